@@ -1,0 +1,190 @@
+"""Synthetic inputs for tests and benchmarks: network weights and PIV particle-image pairs.
+
+No pretrained weights ship with the reference (`.MISSING_LARGE_BLOBS:1-5`), so parity is
+established on *generated* weights loaded through the same state-dict layout the reference's
+factories build (`src/models.py:719-766`).  Everything here is numpy-Philox seeded and keyed
+by the state-dict name, so the same tensors come out on every machine and torch version.
+
+* `state_dict_spec(model)`   -- ordered {name: shape}, same keys/shapes as the reference nets.
+* `generate_weights(model)`  -- flow-calibrated random weights (see below).
+* `particle_pair(H, W, seed)`-- Gaussian-blob particle images following the image model of
+  `src/particle_image_generator.py:30-58` (density 0.05 ppp, d = 1.5 + U[0,1) px,
+  I = 240 exp(-z^2), uint8), second frame displaced by a Lamb-Oseen vortex + uniform shift.
+
+Calibration: with torch's default init the flow stays ~0.005 px and every warp is an identity,
+which tests nothing.  The generator therefore uses variance-preserving conv weights, near-bilinear
+(unit-gain) depthwise deconvolutions, near-one regulariser scale weights and O(0.3) flow heads, so
+that every pyramid level produces a flow update of a visible fraction of a pixel and the final
+field is a few pixels.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+
+K_LEVEL = [0, 7, 7, 5, 5, 3, 3]          # src/models.py:161,205,225
+C_FEAT = [0, 32, 32, 64, 96, 128, 192]   # src/models.py:70-106
+C_MATCH = [0, 64, 64, 64, 96, 128, 192]  # NetC_ext lifts L1/L2 to 64 (src/models.py:124,353-357)
+
+MODEL_CFG = {
+    # src/models.py:729-730 (hui) and :754-755 (piv)
+    "hui": dict(starting_scale=40.0, lowest_level=2,
+                rgb_mean=(0.411618, 0.434631, 0.454253, 0.410782, 0.433645, 0.452793)),
+    "piv": dict(starting_scale=10.0, lowest_level=1,
+                rgb_mean=(0.173935, 0.180594, 0.192608, 0.172978, 0.179518, 0.191300)),
+}
+
+
+def state_dict_spec(model: str = "piv", lowest_level: int | None = None) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Ordered name -> shape map of `LiteFlowNet.state_dict()` (src/models.py:305-317)."""
+    if lowest_level is None:
+        lowest_level = MODEL_CFG[model]["lowest_level"]
+    spec: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(name, cout, cin, kh, kw, bias=True):
+        spec[name + ".weight"] = (cout, cin, kh, kw)
+        if bias:
+            spec[name + ".bias"] = (cout,)
+
+    # NetC (src/models.py:70-106)
+    conv("NetC.conv1.0", 32, 3, 7, 7)
+    conv("NetC.conv2.0", 32, 32, 3, 3); conv("NetC.conv2.2", 32, 32, 3, 3); conv("NetC.conv2.4", 32, 32, 3, 3)
+    conv("NetC.conv3.0", 64, 32, 3, 3); conv("NetC.conv3.2", 64, 64, 3, 3)
+    conv("NetC.conv4.0", 96, 64, 3, 3); conv("NetC.conv4.2", 96, 96, 3, 3)
+    conv("NetC.conv5.0", 128, 96, 3, 3)
+    conv("NetC.conv6.0", 192, 128, 3, 3)
+    # NetC_ext (src/models.py:309-311): one per level in [lowest_level, 2]
+    for i in range(len(range(lowest_level - 1, 2))):
+        conv(f"NetC_ext.{i}.conv_ext.0", 64, 32, 1, 1)
+    levels = list(range(lowest_level, 7))
+    for i, L in enumerate(levels):            # NetE_M (src/models.py:134-163)
+        k = K_LEVEL[L]
+        if L != 6:
+            spec[f"NetE_M.{i}.upConv_M.weight"] = (2, 1, 4, 4)
+        if L < 4:
+            spec[f"NetE_M.{i}.upCorr_M.weight"] = (49, 1, 4, 4)
+        conv(f"NetE_M.{i}.conv_M.0", 128, 49, 3, 3); conv(f"NetE_M.{i}.conv_M.2", 64, 128, 3, 3)
+        conv(f"NetE_M.{i}.conv_M.4", 32, 64, 3, 3); conv(f"NetE_M.{i}.conv_M.6", 2, 32, k, k)
+    for i, L in enumerate(levels):            # NetE_S (src/models.py:190-207)
+        k = K_LEVEL[L]
+        conv(f"NetE_S.{i}.conv_S.0", 128, 2 * C_MATCH[L] + 2, 3, 3); conv(f"NetE_S.{i}.conv_S.2", 64, 128, 3, 3)
+        conv(f"NetE_S.{i}.conv_S.4", 32, 64, 3, 3); conv(f"NetE_S.{i}.conv_S.6", 2, 32, k, k)
+    for i, L in enumerate(levels):            # NetE_R (src/models.py:220-272)
+        k = K_LEVEL[L]
+        if L < 5:
+            conv(f"NetE_R.{i}.moduleFeat.0", 128, C_FEAT[L], 1, 1)
+        cin = 195 if L == 6 else 131
+        conv(f"NetE_R.{i}.conv_R.0", 128, cin, 3, 3); conv(f"NetE_R.{i}.conv_R.2", 128, 128, 3, 3)
+        conv(f"NetE_R.{i}.conv_R.4", 64, 128, 3, 3); conv(f"NetE_R.{i}.conv_R.6", 64, 64, 3, 3)
+        conv(f"NetE_R.{i}.conv_R.8", 32, 64, 3, 3); conv(f"NetE_R.{i}.conv_R.10", 32, 32, 3, 3)
+        if L < 5:
+            conv(f"NetE_R.{i}.conv_dist_R.0", k * k, 32, k, 1); conv(f"NetE_R.{i}.conv_dist_R.1", k * k, k * k, 1, k)
+        else:
+            conv(f"NetE_R.{i}.conv_dist_R.0", k * k, 32, k, k)
+        conv(f"NetE_R.{i}.moduleScaleX", 1, k * k, 1, 1); conv(f"NetE_R.{i}.moduleScaleY", 1, k * k, 1, 1)
+    return spec
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, zlib.crc32(name.encode())]))
+
+
+_BILIN = np.outer([0.25, 0.75, 0.75, 0.25], [0.25, 0.75, 0.75, 0.25]).astype(np.float64)
+
+
+def generate_weights_np(model: str = "piv", seed: int = 0, lowest_level: int | None = None
+                        ) -> "OrderedDict[str, np.ndarray]":
+    """Flow-calibrated random weights as float32 numpy arrays, in state-dict order."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in state_dict_spec(model, lowest_level).items():
+        g = _rng(seed, name)
+        if name.endswith("upConv_M.weight") or name.endswith("upCorr_M.weight"):
+            w = _BILIN[None, None] * (1.0 + 0.05 * g.standard_normal(shape))
+        elif ".moduleScale" in name:
+            w = (1.0 + 0.1 * g.standard_normal(shape)) if name.endswith("weight") else 0.02 * g.standard_normal(shape)
+        elif name.endswith("conv_M.6.bias") or name.endswith("conv_S.6.bias"):
+            w = 0.12 * g.standard_normal(shape)
+        elif name.endswith(".bias"):
+            w = 0.05 * g.standard_normal(shape)
+        else:
+            cout, cin, kh, kw = shape
+            gain = 1.4
+            if name.endswith("conv_M.6.weight") or name.endswith("conv_S.6.weight"):
+                gain = 1.0           # flow heads: O(0.3-1) updates in normalised flow units
+            if ".conv_dist_R." in name:
+                gain = 0.9           # distances of O(1): exp(-d^2) spreads over the patch
+            w = g.standard_normal(shape) * (gain / np.sqrt(cin * kh * kw))
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
+def generate_weights(model: str = "piv", seed: int = 0, lowest_level: int | None = None):
+    """Same as `generate_weights_np` but as an OrderedDict of torch tensors (a loadable state dict)."""
+    import torch
+    return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in generate_weights_np(model, seed, lowest_level).items())
+
+
+def displacement_field(x: np.ndarray, y: np.ndarray, H: int, W: int, peak: float = 4.0,
+                       shift: Tuple[float, float] = (1.5, -0.75)) -> Tuple[np.ndarray, np.ndarray]:
+    """Lamb-Oseen vortex (peak tangential displacement `peak` px) plus a uniform shift, at points (x, y)."""
+    cx, cy = 0.5 * (W - 1), 0.5 * (H - 1)
+    rc = 0.18 * min(H, W)
+    dx, dy = x - cx, y - cy
+    r2 = dx * dx + dy * dy
+    r = np.sqrt(r2) + 1e-12
+    # v_theta(r) = G (1 - exp(-r^2/rc^2)) / r, max at r = 1.1209 rc with value 0.6382 G / rc
+    G = peak * rc / 0.6382
+    vt = G * (1.0 - np.exp(-r2 / (rc * rc))) / r
+    return shift[0] - vt * dy / r, shift[1] + vt * dx / r
+
+
+def _render(xp, yp, zp, dp, H, W) -> np.ndarray:
+    img = np.zeros((H, W), dtype=np.float64)
+    inten = 240.0 * np.exp(-(zp ** 2))
+    rad = 4
+    for x0, y0, a, d in zip(xp, yp, inten, dp):
+        ix, iy = int(np.floor(x0)), int(np.floor(y0))
+        xa, xb = max(ix - rad, 0), min(ix + rad + 2, W)
+        ya, yb = max(iy - rad, 0), min(iy + rad + 2, H)
+        if xa >= xb or ya >= yb:
+            continue
+        xs = np.arange(xa, xb)[None, :] - x0
+        ys = np.arange(ya, yb)[:, None] - y0
+        img[ya:yb, xa:xb] += a * np.exp(-(xs * xs + ys * ys) / ((0.5 * d) ** 2))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def particle_pair(H: int, W: int, seed: int = 1234, density: float = 0.05, peak: float = 4.0,
+                  shift: Tuple[float, float] = (1.5, -0.75)):
+    """Returns (img1, img2, flow): uint8 [H,W] frames and the true displacement [2,H,W] (u, v) in px."""
+    g = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, 0x9E3779B9]))
+    m = 16
+    n = int(np.floor(density * (H + 2 * m) * (W + 2 * m)))
+    xp = g.random(n) * (W + 2 * m) - m
+    yp = g.random(n) * (H + 2 * m) - m
+    zp = g.random(n) - 0.5
+    dp = 1.5 + g.random(n)
+    u, v = displacement_field(xp, yp, H, W, peak, shift)
+    img1 = _render(xp, yp, zp, dp, H, W)
+    img2 = _render(xp + u, yp + v, zp, dp, H, W)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    fu, fv = displacement_field(xx, yy, H, W, peak, shift)
+    return img1, img2, np.stack([fu, fv]).astype(np.float32)
+
+
+def to_input(img_u8: np.ndarray) -> np.ndarray:
+    """uint8 [H,W] -> float32 [3,H,W] in [0,1] (what torchvision's ToTensor gives for a gray image -> RGB)."""
+    f = img_u8.astype(np.float32) / np.float32(255.0)
+    return np.ascontiguousarray(np.broadcast_to(f[None], (3,) + f.shape))
+
+
+def particle_batch(B: int, H: int, W: int, seed: int = 1234):
+    """float32 arrays img1, img2 of shape [B,3,H,W] in [0,1]; frame b uses seed + b."""
+    a, c = [], []
+    for b in range(B):
+        i1, i2, _ = particle_pair(H, W, seed + b)
+        a.append(to_input(i1)); c.append(to_input(i2))
+    return np.stack(a), np.stack(c)
