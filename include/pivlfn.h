@@ -1,0 +1,99 @@
+/*
+ * pivlfn.h -- C ABI of libpivlfn.so: the MI355X (gfx950) PIV-LiteFlowNet inference hot path.
+ *
+ * This is the drop-in boundary for the reference's src/models.py + src/correlation.py.  Every entry
+ * point takes plain device pointers, sizes and a hipStream_t (passed as void*); nothing here
+ * allocates per call (outputs and the workspace are the caller's), every function returns 0 on
+ * success or a non-zero code, and pivlfn_last_error() gives the thread-local message.
+ * All tensors are fp32.  "NCHW" tensors are contiguous, exactly what the reference's Python passes.
+ * Citations are into /root/reference/.
+ */
+#ifndef PIVLFN_H
+#define PIVLFN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIVLFN_OK            0
+#define PIVLFN_ERR_ARG       1   /* bad shape / null pointer / unsupported configuration */
+#define PIVLFN_ERR_HIP       2   /* a HIP runtime call failed (message has the hipError string) */
+#define PIVLFN_ERR_WORKSPACE 3   /* workspace too small */
+#define PIVLFN_ERR_WEIGHTS   4   /* state dict does not match the network layout */
+
+typedef struct pivlfn_net pivlfn_net;   /* opaque: packed weights of one network on one device */
+
+/* One entry of a state dict (host memory, fp32, contiguous).  Same names and shapes as
+ * LiteFlowNet.state_dict() in src/models.py:305-317 (key pattern in SURVEY.md section 8 a10). */
+typedef struct {
+    const char  *name;
+    const float *data;
+    int          ndim;
+    int          shape[4];
+} pivlfn_tensor;
+
+const char *pivlfn_last_error(void);
+int         pivlfn_abi_version(void);
+
+/* ---- custom op: replaces _FunctionCorrelation.forward, src/correlation.py:287-344 (+ kernels :9-104)
+ * first, second: NCHW [B,C,H,W]; out: NCHW [B,49,ceil(H/stride),ceil(W/stride)];
+ * out[b,7(dy+3)+(dx+3),y,x] = (1/C) sum_c first[b,c,s*y,s*x] * second[b,c,s*(y+dy),s*(x+dx)], zeros outside. */
+int pivlfn_corr_fwd(const float *first, const float *second, float *out,
+                    int B, int C, int H, int W, int stride, void *stream);
+
+/* ---- replaces backwarp(), src/models.py:20-35.  in: NCHW [B,C,H,W]; flow: NCHW [B,2,H,W] (pixels);
+ * out[b,c,y,x] = bilinear(in[b,c], x + flow[b,0,y,x], y + flow[b,1,y,x]), zeros outside. */
+int pivlfn_backwarp(const float *in, const float *flow, float *out,
+                    int B, int C, int H, int W, void *stream);
+
+/* ---- fused Matching front end: backwarp(second, flow*flow_scale) then correlation, then optional
+ * LeakyReLU(0.1): src/models.py:171-184.  NCHW in / NCHW out, flow may be NULL (level 6). */
+int pivlfn_warp_corr_fwd(const float *first, const float *second, const float *flow, float flow_scale,
+                         float *out, int B, int C, int H, int W, int stride, int leaky, void *stream);
+
+/* ---- the same kernel on the network's internal channels-last layout (what pivlfn_forward launches;
+ * exported for benchmarks and roofline measurement).  first/second: [B,H,W,C]; flow: [B,H,W,4] (u,v,0,0)
+ * or NULL; out: [B,Ho,Wo,56] (49 displacements + 7 zero lanes). C must be a multiple of 32. */
+int pivlfn_warp_corr_nhwc(const float *first, const float *second, const float *flow, float flow_scale,
+                          float *out, int B, int C, int H, int W, int stride, int leaky, void *stream);
+
+/* ---- bilinear resize, align_corners=False, NCHW -> NCHW, with a per-channel multiplier
+ * (mul[c % 2] when mul != NULL, host pointer to 2 floats): the two interpolate calls and the flow
+ * rescale of estimate(), inference.py:46-49 and :57-61. */
+int pivlfn_resize_bilinear(const float *in, float *out, int B, int C, int H, int W, int Ho, int Wo,
+                           const float *mul, void *stream);
+
+/* ---- network: replaces LiteFlowNet.__init__ + load_state_dict (src/models.py:39-317, 736-738, 762-764).
+ * Uploads and repacks the weights once (this is the only call that allocates device memory).
+ * starting_scale / lowest_level / rgb_mean as in the factories src/models.py:729-730, 754-755. */
+int pivlfn_create(const pivlfn_tensor *tensors, int n_tensors, float starting_scale, int lowest_level,
+                  const float rgb_mean[6], pivlfn_net **out);
+int pivlfn_destroy(pivlfn_net *net);
+
+/* Bytes of scratch pivlfn_forward needs for a [B,3,H,W] pair batch (H, W multiples of 32). */
+size_t pivlfn_workspace_bytes(const pivlfn_net *net, int B, int H, int W);
+
+/* ---- replaces LiteFlowNet.forward in eval mode, src/models.py:319-370.
+ * img1, img2: NCHW [B,3,H,W] in [0,1] (NOT modified: the reference's in-place mean subtraction
+ * :321-323 happens on an internal copy).  flow: NCHW [B,2,H/2^(lowest_level-1),W/2^(lowest_level-1)],
+ * already multiplied by SCALEFACTOR[1] (:370).
+ * levels (optional, may be NULL): receives the per-level [M,S,R] flows of the training-mode return
+ * (:363-367), coarsest level first, each NCHW [B,2,h,w], packed back to back. */
+int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels,
+                   int B, int H, int W, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Number of floats `levels` must hold for pivlfn_forward. */
+size_t pivlfn_levels_floats(const pivlfn_net *net, int B, int H, int W);
+
+/* ---- measurement hooks.  With profiling on, pivlfn_forward brackets the level-`level` warp+correlation
+ * launch with hipEvents on `stream`; pivlfn_profile_read() synchronises those events and returns the
+ * accumulated milliseconds and launch count since the last reset. */
+int pivlfn_profile_enable(pivlfn_net *net, int level);   /* level 1..6, 0 = off */
+int pivlfn_profile_read(pivlfn_net *net, double *ms_total, long *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIVLFN_H */

@@ -1,0 +1,99 @@
+// extern "C" surface of libpivlfn.so (declared in include/pivlfn.h).
+#include <vector>
+#include "common.h"
+
+struct pivlfn_net;
+
+namespace pivlfn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lowest, const float mean[6], pivlfn_net **out);
+size_t net_workspace_bytes(const pivlfn_net *net, int B, int H, int W);
+size_t net_levels_floats(const pivlfn_net *net, int B, int H, int W);
+int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels, int B, int H, int W,
+                void *ws, size_t ws_bytes, hipStream_t st);
+int net_destroy(pivlfn_net *net);
+int net_profile_enable(pivlfn_net *net, int level);
+int net_profile_read(pivlfn_net *net, double *ms, long *launches, int reset);
+
+}  // namespace pivlfn
+
+using namespace pivlfn;
+
+extern "C" {
+
+const char *pivlfn_last_error(void) { return g_err; }
+int pivlfn_abi_version(void) { return 1; }
+
+int pivlfn_corr_fwd(const float *first, const float *second, float *out, int B, int C, int H, int W, int stride, void *stream)
+{
+    return launch_warp_corr(first, second, nullptr, 0.f, out, B, C, H, W, stride, 0, false, (hipStream_t)stream);
+}
+
+int pivlfn_backwarp(const float *in, const float *flow, float *out, int B, int C, int H, int W, void *stream)
+{
+    return launch_backwarp_nchw(in, flow, out, B, C, H, W, (hipStream_t)stream);
+}
+
+int pivlfn_warp_corr_fwd(const float *first, const float *second, const float *flow, float flow_scale, float *out,
+                         int B, int C, int H, int W, int stride, int leaky, void *stream)
+{
+    return launch_warp_corr(first, second, flow, flow_scale, out, B, C, H, W, stride, leaky, false, (hipStream_t)stream);
+}
+
+int pivlfn_warp_corr_nhwc(const float *first, const float *second, const float *flow, float flow_scale, float *out,
+                          int B, int C, int H, int W, int stride, int leaky, void *stream)
+{
+    return launch_warp_corr(first, second, flow, flow_scale, out, B, C, H, W, stride, leaky, true, (hipStream_t)stream);
+}
+
+int pivlfn_resize_bilinear(const float *in, float *out, int B, int C, int H, int W, int Ho, int Wo, const float *mul,
+                           void *stream)
+{
+    return launch_resize_nchw(in, out, B, C, H, W, Ho, Wo, mul ? mul[0] : 1.f, mul ? mul[1] : 1.f, mul ? 1 : 0,
+                              (hipStream_t)stream);
+}
+
+int pivlfn_create(const pivlfn_tensor *tensors, int n_tensors, float starting_scale, int lowest_level,
+                  const float rgb_mean[6], pivlfn_net **out)
+{
+    return net_create(tensors, n_tensors, starting_scale, lowest_level, rgb_mean, out);
+}
+
+int pivlfn_destroy(pivlfn_net *net) { return net_destroy(net); }
+
+size_t pivlfn_workspace_bytes(const pivlfn_net *net, int B, int H, int W)
+{
+    if (!net || B <= 0 || H <= 0 || W <= 0) return 0;
+    return net_workspace_bytes(net, B, H, W);
+}
+
+size_t pivlfn_levels_floats(const pivlfn_net *net, int B, int H, int W)
+{
+    if (!net || B <= 0 || H <= 0 || W <= 0) return 0;
+    return net_levels_floats(net, B, H, W);
+}
+
+int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels, int B, int H, int W,
+                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    return net_forward(net, img1, img2, flow, levels, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pivlfn_profile_enable(pivlfn_net *net, int level) { return net_profile_enable(net, level); }
+
+int pivlfn_profile_read(pivlfn_net *net, double *ms_total, long *launches, int reset)
+{
+    return net_profile_read(net, ms_total, launches, reset);
+}
+
+}  // extern "C"

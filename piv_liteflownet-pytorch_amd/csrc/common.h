@@ -1,0 +1,119 @@
+// Shared declarations for the gfx950 kernels of libpivlfn.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/pivlfn.h"
+
+namespace pivlfn {
+
+void set_error(const char *fmt, ...);
+
+#define PIV_CHECK_HIP(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            pivlfn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PIVLFN_ERR_HIP;                                                           \
+        }                                                                                    \
+    } while (0)
+
+#define PIV_REQUIRE(cond, ...)                                                               \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            pivlfn::set_error(__VA_ARGS__);                                                  \
+            return PIVLFN_ERR_ARG;                                                           \
+        }                                                                                    \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Blocks b and b+8 share an XCD (round-robin dispatch over the 8 XCDs); give every XCD a contiguous
+// run of logical tile ids so neighbouring tiles (shared halos) hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n)
+{
+    const int q = n >> 3, r = n & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+__device__ __forceinline__ float lrelu01(float v) { return v >= 0.f ? v : 0.1f * v; }
+
+// Bilinear taps of a back-warp sample at (fx, fy): pixel indices (y*W+x) of the four neighbours, -1 when the
+// neighbour lies outside the image (padding_mode='zeros', align_corners=True: src/models.py:32-35).
+struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+__device__ __forceinline__ Taps make_taps(float fx, float fy, int H, int W)
+{
+    Taps t;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float ax = fx - x0f, ay = fy - y0f;
+    // clamp before the int conversion so wild flows cannot overflow; anything clamped is out of range anyway
+    const int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)W);
+    const int y0 = (int)fminf(fmaxf(y0f, -2.f), (float)H);
+    const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool ya = y0 >= 0 && y0 < H, yb = y0 + 1 >= 0 && y0 + 1 < H;
+    t.o00 = (xa && ya) ? y0 * W + x0 : -1;
+    t.o01 = (xb && ya) ? y0 * W + x0 + 1 : -1;
+    t.o10 = (xa && yb) ? (y0 + 1) * W + x0 : -1;
+    t.o11 = (xb && yb) ? (y0 + 1) * W + x0 + 1 : -1;
+    t.w00 = (1.f - ax) * (1.f - ay);
+    t.w01 = ax * (1.f - ay);
+    t.w10 = (1.f - ax) * ay;
+    t.w11 = ax * ay;
+    return t;
+}
+
+// ---- convolution (conv_mfma.hip) -------------------------------------------------------------------
+struct ConvSeg {
+    const float *ptr;   // NHWC base, channel offset already applied
+    int cload;          // channels staged from this source, multiple of 4 (zero-weight lanes allowed)
+    int stride;         // floats between consecutive pixels
+};
+
+struct ConvParams {
+    ConvSeg seg[3];
+    int nseg;
+    const float *wpk;   // [nchunk][KH*KW][2][cout_pad][4]
+    const float *bias;  // [cout_pad]
+    float *out;         // NHWC, channel offset applied
+    int out_stride;     // floats per output pixel
+    int cout_store;     // channels written per pixel (>= real Cout; the extra ones are exact zeros)
+    int cout_pad;       // multiple of 32, >= cout_store
+    const float *res;   // optional residual added before the activation (same pixel grid as out)
+    int res_stride;
+    int B, H, W;        // input
+    int Ho, Wo;         // output
+    int KH, KW, S, padY, padX;
+    int nchunk;         // K chunks of 8 input channels over all segments
+    int lrelu;
+};
+
+int launch_conv(const ConvParams &p, hipStream_t st);
+
+// ---- warp + correlation (warp_corr.hip) ------------------------------------------------------------
+int launch_warp_corr(const float *f1, const float *f2, const float *flow, float flow_scale, float *out,
+                     int B, int C, int H, int W, int stride, int leaky, bool nhwc, hipStream_t st);
+int launch_backwarp_nchw(const float *in, const float *flow, float *out, int B, int C, int H, int W, hipStream_t st);
+
+// ---- small ops (ops.hip); NHWC unless noted ----------------------------------------------------------
+int launch_prep_images(const float *img1, const float *img2, float *out, int B, int H, int W,
+                       const float mean[6], hipStream_t st);                       // NCHW x2 -> [2B,H,W,4]
+int launch_resize_nhwc4(const float *in, float *out, int N, int H, int W, int Ho, int Wo, hipStream_t st);
+int launch_resize_nchw(const float *in, float *out, int B, int C, int H, int W, int Ho, int Wo,
+                       float m0, float m1, int use_mul, hipStream_t st);
+int launch_dwconvT(const float *in, const float *w, float *out, int B, int H, int W, int C, int stride_in,
+                   int stride_out, int cstore, hipStream_t st);                    // k4 s2 p1 depthwise
+int launch_backwarp_nhwc(const float *in, const float *flow4, float scale, float *out, int B, int H, int W,
+                         int C, hipStream_t st);
+int launch_flow_mean(const float *flow4, float *partial, float *mean, int B, int HW, hipStream_t st);
+int launch_reg_prep(const float *img1, const float *img2, const float *flow4, const float *mean, float scale,
+                    float *misc4, int B, int H, int W, hipStream_t st);
+int launch_reg_tail(const float *dist, int dstride, const float *flow4, const float *wx, const float *wy,
+                    float bx, float by, int k, float *out4, float *out_nchw, float out_scale,
+                    int B, int H, int W, hipStream_t st);
+int launch_flow4_to_nchw(const float *flow4, float *out, int B, int H, int W, hipStream_t st);
+int flow_mean_partials(int HW);
+
+}  // namespace pivlfn

@@ -1,0 +1,191 @@
+// Direct (im2col-free) NHWC fp32 convolution on the gfx950 fp32 matrix cores.
+//
+// Covers every dense conv on the LiteFlowNet path (reference: torch.nn.Conv2d call sites in
+// /root/reference/src/models.py:70-106, 124, 154-163, 197-207, 229-272): 3x3 s1/s2, 1x1, 7x7, kxk flow
+// heads, (kx1)/(1xk) separable pairs; bias, optional LeakyReLU(0.1) and optional residual fused in the
+// epilogue; up to three input sources so the concatenations of src/models.py:216 and :280 never
+// materialise.
+//
+// Formulation: implicit GEMM  D[pixel][cout] = sum_{tap, cin} X[pixel+tap][cin] * W[cout][cin][tap]
+//   * one workgroup = 4 waves = a TH x 32 output-pixel tile (TH = 4*MT rows) x BN = 32*NT channels;
+//   * K is walked in chunks of 8 input channels: the (TH*S+KH-1) x (32*S+KW-1) x 8 input patch is staged
+//     ONCE per chunk into LDS and reused by all KH*KW taps (this is what makes it im2col-free), together
+//     with the chunk's [tap][8][BN] weight slab;
+//   * v_mfma_f32_32x32x2_f32: A = 32 consecutive output pixels of one row, B = 32 output channels.
+//     Each lane fetches 4 consecutive k with one ds_read_b128 and feeds them to 4 MFMAs, so MFMA j of a
+//     chunk contracts input channels {j, 4+j}: a permutation of the k order inside a chunk, exact fp32
+//     fma chains (the matrix core rounds once per product like fmaf).
+//   * LDS pixel pitch is 12 floats (8 + 4 pad): the 16-lane groups of ds_read_b128 hit 16 distinct
+//     16-byte slots, conflict-free at stride 1.
+//   * accumulator layout (32x32): lane&31 = channel, so every epilogue store instruction writes two
+//     full 128-byte channel runs.
+#include "common.h"
+
+namespace pivlfn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int PIXP = 12;
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = NT * 32;
+    constexpr int TH = 4 * MT;
+    const int taps = p.KH * p.KW;
+    const int PH = (TH - 1) * p.S + p.KH;
+    const int PW = 31 * p.S + p.KW;
+    float *patch = smem;
+    float *wts = smem + PH * PW * PIXP;
+
+    const int tiles_x = (p.Wo + 31) >> 5;
+    const int tiles_y = (p.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int n0 = blockIdx.y * BN;
+    const int x0 = tx * 32, y0 = ty * TH;
+    const int ix0 = x0 * p.S - p.padX, iy0 = y0 * p.S - p.padY;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, hh = lane >> 5;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = ((wave * MT + m) * p.S * PW + row * p.S) * PIXP + hh * 4;
+    const int bbase = (hh * BN + row) * 4;
+
+    const int npix = PH * PW;
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk);
+    int chunk = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+        const float *sp = p.seg[s].ptr;
+        const int scl = p.seg[s].cload, sst = p.seg[s].stride;
+        for (int c0 = 0; c0 < scl; c0 += 8, ++chunk) {
+            if (chunk) __syncthreads();
+            for (int idx = tid; idx < npix * 2; idx += 256) {
+                const int pix = idx >> 1, q = idx & 1;
+                const int py = pix / PW, px = pix - py * PW;
+                const int iy = iy0 + py, ix = ix0 + px, c = c0 + q * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < scl)
+                    v = *reinterpret_cast<const f32x4 *>(sp + (size_t)((b * p.H + iy) * p.W + ix) * sst + c);
+                *reinterpret_cast<f32x4 *>(patch + pix * PIXP + q * 4) = v;
+            }
+            const f32x4 *wc = wsrc + (size_t)chunk * taps * 2 * p.cout_pad + n0;
+            for (int idx = tid; idx < taps * 2 * BN; idx += 256) {
+                const int th = idx / BN, n = idx - th * BN;
+                reinterpret_cast<f32x4 *>(wts)[idx] = wc[(size_t)th * p.cout_pad + n];
+            }
+            __syncthreads();
+            int tap = 0;
+            for (int ky = 0; ky < p.KH; ++ky) {
+                for (int kx = 0; kx < p.KW; ++kx, ++tap) {
+                    const int toff = (ky * PW + kx) * PIXP;
+                    f32x4 a[MT], bq[NT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4 *>(patch + abase[m] + toff);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        bq[n] = *reinterpret_cast<const f32x4 *>(wts + tap * 2 * BN * 4 + bbase + n * 128);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bq[n][j], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: bias, residual, activation, masked NHWC store
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ch = n0 + n * 32 + row;
+        if (ch >= p.cout_store) continue;
+        const float bias = p.bias[ch];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + wave * MT + m;
+            if (oy >= p.Ho) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ox >= p.Wo) continue;
+                const size_t pix = (size_t)(b * p.Ho + oy) * p.Wo + ox;
+                float v = acc[m][n][r] + bias;
+                if (p.res) v += p.res[pix * p.res_stride + ch];
+                if (p.lrelu) v = lrelu01(v);
+                p.out[pix * p.out_stride + ch] = v;
+            }
+        }
+    }
+}
+
+template <int MT, int NT>
+static int launch_t(const ConvParams &p, hipStream_t st)
+{
+    constexpr int TH = 4 * MT, BN = NT * 32;
+    const int PH = (TH - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
+    const size_t lds = ((size_t)PH * PW * PIXP + (size_t)p.KH * p.KW * 2 * BN * 4) * sizeof(float);
+    PIV_REQUIRE(lds <= 160 * 1024, "conv: LDS tile of %zu bytes exceeds 160 KiB (k=%dx%d s=%d)", lds, p.KH, p.KW, p.S);
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<MT, NT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        attr_set = 160 * 1024;
+    }
+    const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
+    dim3 grid(tiles, p.cout_pad / BN);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+int launch_conv(const ConvParams &p, hipStream_t st)
+{
+    PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3, "conv: nseg=%d", p.nseg);
+    PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad, "conv: cout_pad=%d cout_store=%d", p.cout_pad, p.cout_store);
+    PIV_REQUIRE(p.B > 0 && p.H > 0 && p.W > 0 && p.Ho > 0 && p.Wo > 0, "conv: empty shape");
+    for (int s = 0; s < p.nseg; ++s)
+        PIV_REQUIRE(p.seg[s].cload % 4 == 0 && p.seg[s].stride % 4 == 0 && p.seg[s].ptr, "conv: segment %d misaligned", s);
+    int nt;
+    if (p.cout_pad % 128 == 0) nt = 4;
+    else if (p.cout_pad % 96 == 0) nt = 3;
+    else if (p.cout_pad % 64 == 0) nt = 2;
+    else nt = 1;
+    // Two output rows per wave when that still leaves a full chip's worth of workgroups.
+    const long blocks2 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B * (p.cout_pad / (nt * 32));
+    const bool big = blocks2 >= 512 && (p.KH * p.KW <= 25 || nt == 1);
+    if (big) {
+        switch (nt) {
+            case 4: return launch_t<2, 4>(p, st);
+            case 3: return launch_t<2, 3>(p, st);
+            case 2: return launch_t<2, 2>(p, st);
+            default: return launch_t<2, 1>(p, st);
+        }
+    }
+    switch (nt) {
+        case 4: return launch_t<1, 4>(p, st);
+        case 3: return launch_t<1, 3>(p, st);
+        case 2: return launch_t<1, 2>(p, st);
+        default: return launch_t<1, 1>(p, st);
+    }
+}
+
+}  // namespace pivlfn

@@ -1,0 +1,425 @@
+// Network object behind pivlfn_create / pivlfn_forward: weight repacking, workspace plan and the
+// coarse-to-fine level pipeline of LiteFlowNet.forward (/root/reference/src/models.py:319-370) expressed as a
+// fixed sequence of gfx950 kernel launches on one stream.  No allocation, no host sync inside forward.
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace pivlfn {
+
+static const int K_LEVEL[7] = {0, 7, 7, 5, 5, 3, 3};            // src/models.py:161,205,225
+static const int C_FEAT[7] = {0, 32, 32, 64, 96, 128, 192};     // src/models.py:70-106
+static const int C_MATCH[7] = {0, 64, 64, 64, 96, 128, 192};    // NetC_ext: src/models.py:124,353-357
+
+static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+struct ConvW {
+    float *wpk = nullptr, *bias = nullptr;
+    int cout = 0, cout_pad = 0, KH = 0, KW = 0, nchunk = 0;
+};
+
+struct LevelW {
+    float *upconv = nullptr, *upcorr = nullptr;    // depthwise k4 weights [C4][16]
+    ConvW M[4], S[4], R[6], feat, dist0, dist1;
+    float *wx = nullptr, *wy = nullptr;
+    float bx = 0.f, by = 0.f;
+};
+
+}  // namespace pivlfn
+
+struct pivlfn_net {
+    float scale[7];
+    int lowest;
+    float mean[6];
+    pivlfn::ConvW netc[10];
+    pivlfn::ConvW ext[3];          // index by level (1,2)
+    pivlfn::LevelW lv[7];
+    std::vector<void *> allocs;
+    // measurement hooks
+    int prof_level = 0;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    long ev_dropped = 0;
+};
+
+namespace pivlfn {
+
+typedef std::map<std::string, const pivlfn_tensor *> TMap;
+
+static int upload(pivlfn_net *net, const std::vector<float> &h, float **dev)
+{
+    void *d = nullptr;
+    PIV_CHECK_HIP(hipMalloc(&d, h.size() * sizeof(float)));
+    net->allocs.push_back(d);
+    PIV_CHECK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dev = (float *)d;
+    return PIVLFN_OK;
+}
+
+static const pivlfn_tensor *find(const TMap &m, const std::string &name, int d0, int d1, int d2, int d3, int ndim)
+{
+    auto it = m.find(name);
+    if (it == m.end()) {
+        set_error("state dict: missing key '%s'", name.c_str());
+        return nullptr;
+    }
+    const pivlfn_tensor *t = it->second;
+    const int want[4] = {d0, d1, d2, d3};
+    bool ok = t->ndim == ndim && t->data != nullptr;
+    for (int i = 0; ok && i < ndim; ++i) ok = t->shape[i] == want[i];
+    if (!ok) {
+        set_error("state dict: '%s' has the wrong shape (want [%d,%d,%d,%d] ndim %d)", name.c_str(), d0, d1, d2, d3, ndim);
+        return nullptr;
+    }
+    return t;
+}
+
+struct SegDef { int creal, cload; };
+
+// OIHW weights -> [chunk][tap][half][cout_pad][4]; chunk = 8 staged input channels of one source.
+// Element (chunk, tap, h, n, j) multiplies staged channel 8*chunk_in_seg + 4*h + j of that source.
+static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, int cout, int cin, int kh, int kw,
+                     const std::vector<SegDef> &segs, ConvW *out)
+{
+    const pivlfn_tensor *w = find(m, name + ".weight", cout, cin, kh, kw, 4);
+    const pivlfn_tensor *b = find(m, name + ".bias", cout, 0, 0, 0, 1);
+    if (!w || !b) return PIVLFN_ERR_WEIGHTS;
+    int creal = 0, nchunk = 0;
+    for (auto &s : segs) { creal += s.creal; nchunk += (s.cload + 7) / 8; }
+    if (creal != cin) { set_error("internal: segment channels %d != cin %d for %s", creal, cin, name.c_str()); return PIVLFN_ERR_WEIGHTS; }
+    const int taps = kh * kw, cp = rup(cout, 32);
+    std::vector<float> pk((size_t)nchunk * taps * 2 * cp * 4, 0.f), bias(cp, 0.f);
+    int chunk = 0, coff = 0;
+    for (auto &s : segs) {
+        for (int c0 = 0; c0 < s.cload; c0 += 8, ++chunk)
+            for (int t = 0; t < taps; ++t)
+                for (int h = 0; h < 2; ++h)
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + 4 * h + j;
+                        if (c >= s.creal) continue;
+                        for (int n = 0; n < cout; ++n)
+                            pk[((((size_t)chunk * taps + t) * 2 + h) * cp + n) * 4 + j] =
+                                w->data[((size_t)n * cin + coff + c) * taps + t];
+                    }
+        coff += s.creal;
+    }
+    for (int n = 0; n < cout; ++n) bias[n] = b->data[n];
+    out->cout = cout; out->cout_pad = cp; out->KH = kh; out->KW = kw; out->nchunk = nchunk;
+    int rc = upload(net, pk, &out->wpk);
+    if (rc) return rc;
+    return upload(net, bias, &out->bias);
+}
+
+static int pack_dw(pivlfn_net *net, const TMap &m, const std::string &name, int C, int cpad, float **dev)
+{
+    const pivlfn_tensor *w = find(m, name, C, 1, 4, 4, 4);
+    if (!w) return PIVLFN_ERR_WEIGHTS;
+    std::vector<float> h((size_t)cpad * 16, 0.f);
+    for (int c = 0; c < C; ++c)
+        for (int t = 0; t < 16; ++t) h[(size_t)c * 16 + t] = w->data[(size_t)c * 16 + t];
+    return upload(net, h, dev);
+}
+
+int net_destroy(pivlfn_net *net)
+{
+    if (!net) return PIVLFN_OK;
+    for (void *p : net->allocs) (void)hipFree(p);
+    for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
+    delete net;
+    return PIVLFN_OK;
+}
+
+// hipEvent pairs around the chosen level's warp+correlation launch; read back after the timed region.
+int net_profile_enable(pivlfn_net *net, int level)
+{
+    PIV_REQUIRE(net && level >= 0 && level <= 6, "profile_enable: bad arguments");
+    net->prof_level = level;
+    if (level && net->ev.empty()) {
+        net->ev.resize(2 * 4096);
+        for (auto &e : net->ev) PIV_CHECK_HIP(hipEventCreate(&e));
+    }
+    net->ev_used = 0;
+    net->ev_dropped = 0;
+    return PIVLFN_OK;
+}
+
+int net_profile_read(pivlfn_net *net, double *ms, long *launches, int reset)
+{
+    PIV_REQUIRE(net && ms && launches, "profile_read: null argument");
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < net->ev_used; i += 2) {
+        PIV_CHECK_HIP(hipEventSynchronize(net->ev[i + 1]));
+        float t = 0.f;
+        PIV_CHECK_HIP(hipEventElapsedTime(&t, net->ev[i], net->ev[i + 1]));
+        tot += t;
+    }
+    *ms = tot;
+    *launches = (long)(net->ev_used / 2);
+    if (reset) { net->ev_used = 0; net->ev_dropped = 0; }
+    return PIVLFN_OK;
+}
+
+int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lowest, const float mean[6], pivlfn_net **out)
+{
+    PIV_REQUIRE(tensors && n > 0 && out && mean, "create: null argument");
+    PIV_REQUIRE(lowest >= 1 && lowest <= 6, "create: lowest_level=%d out of range", lowest);
+    TMap m;
+    for (int i = 0; i < n; ++i) {
+        PIV_REQUIRE(tensors[i].name, "create: tensor %d has no name", i);
+        m[tensors[i].name] = &tensors[i];
+    }
+    pivlfn_net *net = new pivlfn_net();
+    net->lowest = lowest;
+    for (int L = 0; L < 7; ++L) net->scale[L] = starting_scale / (float)(1 << L);     // src/models.py:61-63
+    for (int i = 0; i < 6; ++i) net->mean[i] = mean[i];
+#define TRY(expr) do { int _rc = (expr); if (_rc) { net_destroy(net); return _rc; } } while (0)
+    // NetC (src/models.py:70-106); conv1 reads the 4-lane padded image
+    struct { const char *name; int cout, cin, k; } nc[10] = {
+        {"NetC.conv1.0", 32, 3, 7}, {"NetC.conv2.0", 32, 32, 3}, {"NetC.conv2.2", 32, 32, 3}, {"NetC.conv2.4", 32, 32, 3},
+        {"NetC.conv3.0", 64, 32, 3}, {"NetC.conv3.2", 64, 64, 3}, {"NetC.conv4.0", 96, 64, 3}, {"NetC.conv4.2", 96, 96, 3},
+        {"NetC.conv5.0", 128, 96, 3}, {"NetC.conv6.0", 192, 128, 3}};
+    for (int i = 0; i < 10; ++i)
+        TRY(pack_conv(net, m, nc[i].name, nc[i].cout, nc[i].cin, nc[i].k, nc[i].k, {{nc[i].cin, rup(nc[i].cin, 4)}}, &net->netc[i]));
+    // NetC_ext (src/models.py:309-311, 353-355): idx = L-1; NetC_ext[idx-1], python negative index for L1
+    const int n_ext = lowest <= 2 ? 2 - (lowest - 1) : 0;
+    for (int L = lowest; L <= 2; ++L) {
+        int j = (L - 1) - 1;
+        if (j < 0) j += n_ext;
+        TRY(pack_conv(net, m, "NetC_ext." + std::to_string(j) + ".conv_ext.0", 64, 32, 1, 1, {{32, 32}}, &net->ext[L]));
+    }
+    for (int L = lowest; L <= 6; ++L) {
+        const int i = L - lowest, k = K_LEVEL[L], cm = C_MATCH[L];
+        LevelW &lw = net->lv[L];
+        const std::string pm = "NetE_M." + std::to_string(i) + ".", ps = "NetE_S." + std::to_string(i) + ".",
+                          pr = "NetE_R." + std::to_string(i) + ".";
+        if (L != 6) TRY(pack_dw(net, m, pm + "upConv_M.weight", 2, 4, &lw.upconv));
+        if (L < 4) TRY(pack_dw(net, m, pm + "upCorr_M.weight", 49, 56, &lw.upcorr));
+        TRY(pack_conv(net, m, pm + "conv_M.0", 128, 49, 3, 3, {{49, 56}}, &lw.M[0]));
+        TRY(pack_conv(net, m, pm + "conv_M.2", 64, 128, 3, 3, {{128, 128}}, &lw.M[1]));
+        TRY(pack_conv(net, m, pm + "conv_M.4", 32, 64, 3, 3, {{64, 64}}, &lw.M[2]));
+        TRY(pack_conv(net, m, pm + "conv_M.6", 2, 32, k, k, {{32, 32}}, &lw.M[3]));
+        TRY(pack_conv(net, m, ps + "conv_S.0", 128, 2 * cm + 2, 3, 3, {{cm, cm}, {cm, cm}, {2, 4}}, &lw.S[0]));
+        TRY(pack_conv(net, m, ps + "conv_S.2", 64, 128, 3, 3, {{128, 128}}, &lw.S[1]));
+        TRY(pack_conv(net, m, ps + "conv_S.4", 32, 64, 3, 3, {{64, 64}}, &lw.S[2]));
+        TRY(pack_conv(net, m, ps + "conv_S.6", 2, 32, k, k, {{32, 32}}, &lw.S[3]));
+        const int cfr = L < 5 ? 128 : C_FEAT[L];
+        if (L < 5) TRY(pack_conv(net, m, pr + "moduleFeat.0", 128, C_FEAT[L], 1, 1, {{C_FEAT[L], C_FEAT[L]}}, &lw.feat));
+        TRY(pack_conv(net, m, pr + "conv_R.0", 128, 3 + cfr, 3, 3, {{3, 4}, {cfr, cfr}}, &lw.R[0]));
+        TRY(pack_conv(net, m, pr + "conv_R.2", 128, 128, 3, 3, {{128, 128}}, &lw.R[1]));
+        TRY(pack_conv(net, m, pr + "conv_R.4", 64, 128, 3, 3, {{128, 128}}, &lw.R[2]));
+        TRY(pack_conv(net, m, pr + "conv_R.6", 64, 64, 3, 3, {{64, 64}}, &lw.R[3]));
+        TRY(pack_conv(net, m, pr + "conv_R.8", 32, 64, 3, 3, {{64, 64}}, &lw.R[4]));
+        TRY(pack_conv(net, m, pr + "conv_R.10", 32, 32, 3, 3, {{32, 32}}, &lw.R[5]));
+        const int kk = k * k;
+        if (L < 5) {
+            TRY(pack_conv(net, m, pr + "conv_dist_R.0", kk, 32, k, 1, {{32, 32}}, &lw.dist0));
+            TRY(pack_conv(net, m, pr + "conv_dist_R.1", kk, kk, 1, k, {{kk, rup(kk, 4)}}, &lw.dist1));
+        } else {
+            TRY(pack_conv(net, m, pr + "conv_dist_R.0", kk, 32, k, k, {{32, 32}}, &lw.dist0));
+        }
+        const pivlfn_tensor *wx = find(m, pr + "moduleScaleX.weight", 1, kk, 1, 1, 4), *bx = find(m, pr + "moduleScaleX.bias", 1, 0, 0, 0, 1);
+        const pivlfn_tensor *wy = find(m, pr + "moduleScaleY.weight", 1, kk, 1, 1, 4), *by = find(m, pr + "moduleScaleY.bias", 1, 0, 0, 0, 1);
+        if (!wx || !bx || !wy || !by) { net_destroy(net); return PIVLFN_ERR_WEIGHTS; }
+        TRY(upload(net, std::vector<float>(wx->data, wx->data + kk), &lw.wx));
+        TRY(upload(net, std::vector<float>(wy->data, wy->data + kk), &lw.wy));
+        lw.bx = bx->data[0];
+        lw.by = by->data[0];
+    }
+#undef TRY
+    *out = net;
+    return PIVLFN_OK;
+}
+
+// ---- workspace plan -------------------------------------------------------------------------------------------
+struct Plan {
+    size_t off = 0;
+    char *base = nullptr;
+    float *take(size_t floats)
+    {
+        float *p = base ? reinterpret_cast<float *>(base + off) : nullptr;
+        off += (floats * sizeof(float) + 255) / 256 * 256;
+        return p;
+    }
+};
+
+struct Buffers {
+    float *img[7], *feat[7], *ext[3], *sa, *sb;
+    float *flowA, *flowB, *flow_up, *flowM, *flowS, *corr, *corr_up, *t128a, *t128b, *t64a, *t64b, *t32a, *t32b,
+        *f2w, *featR, *misc4, *d1, *dist, *partial, *mean;
+};
+
+static void plan(const pivlfn_net *net, int B, int H, int W, Plan &pl, Buffers &bf)
+{
+    int h[7], w[7];
+    for (int L = 1; L <= 6; ++L) { h[L] = H >> (L - 1); w[L] = W >> (L - 1); }
+    const size_t N2 = 2 * (size_t)B;
+    for (int L = 1; L <= 6; ++L) bf.img[L] = pl.take(N2 * h[L] * w[L] * 4);
+    for (int L = 1; L <= 6; ++L) bf.feat[L] = pl.take(N2 * h[L] * w[L] * C_FEAT[L]);
+    for (int L = 1; L <= 2; ++L) bf.ext[L] = L >= net->lowest ? pl.take(N2 * h[L] * w[L] * 64) : nullptr;
+    bf.sa = pl.take(N2 * h[2] * w[2] * 32);
+    bf.sb = pl.take(N2 * h[2] * w[2] * 32);
+    const int ll = net->lowest;
+    const size_t px = (size_t)B * h[ll] * w[ll];
+    size_t f2w = 0;
+    for (int L = ll; L <= 6; ++L) f2w = std::max(f2w, (size_t)B * h[L] * w[L] * C_MATCH[L]);
+    bf.flowA = pl.take(px * 4); bf.flowB = pl.take(px * 4); bf.flow_up = pl.take(px * 4);
+    bf.flowM = pl.take(px * 4); bf.flowS = pl.take(px * 4);
+    bf.corr = pl.take(px * 56); bf.corr_up = pl.take(px * 56);
+    bf.t128a = pl.take(px * 128); bf.t128b = pl.take(px * 128);
+    bf.t64a = pl.take(px * 64); bf.t64b = pl.take(px * 64);
+    bf.t32a = pl.take(px * 32); bf.t32b = pl.take(px * 32);
+    bf.f2w = pl.take(f2w);
+    bf.featR = pl.take(px * 128);
+    bf.misc4 = pl.take(px * 4);
+    bf.d1 = pl.take(px * 56); bf.dist = pl.take(px * 56);
+    bf.partial = pl.take((size_t)B * flow_mean_partials(0) * 2);
+    bf.mean = pl.take((size_t)B * 2);
+}
+
+size_t net_workspace_bytes(const pivlfn_net *net, int B, int H, int W)
+{
+    Plan pl; Buffers bf;
+    plan(net, B, H, W, pl, bf);
+    return pl.off;
+}
+
+size_t net_levels_floats(const pivlfn_net *net, int B, int H, int W)
+{
+    size_t n = 0;
+    for (int L = net->lowest; L <= 6; ++L) n += (size_t)3 * B * 2 * (H >> (L - 1)) * (W >> (L - 1));
+    return n;
+}
+
+static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out, int out_stride, int cout_store,
+                const float *res, int res_stride, int lrelu, int B, int H, int W, int S, int padY, int padX, hipStream_t st)
+{
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    int i = 0;
+    for (auto &s : segs) p.seg[i++] = s;
+    p.nseg = i;
+    p.wpk = cw.wpk; p.bias = cw.bias; p.out = out; p.out_stride = out_stride; p.cout_store = cout_store;
+    p.cout_pad = cw.cout_pad; p.res = res; p.res_stride = res_stride;
+    p.B = B; p.H = H; p.W = W;
+    p.KH = cw.KH; p.KW = cw.KW; p.S = S; p.padY = padY; p.padX = padX;
+    p.Ho = (H + 2 * padY - cw.KH) / S + 1;
+    p.Wo = (W + 2 * padX - cw.KW) / S + 1;
+    p.nchunk = cw.nchunk; p.lrelu = lrelu;
+    return launch_conv(p, st);
+}
+
+int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels, int B, int H, int W,
+                void *ws, size_t ws_bytes, hipStream_t st)
+{
+    PIV_REQUIRE(net && img1 && img2 && flow && ws, "forward: null argument");
+    PIV_REQUIRE(B > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
+                "forward: H=%d W=%d must be positive multiples of 32 (use estimate() for other sizes)", H, W);
+    PIV_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "forward: workspace must be 256-byte aligned");
+    Plan pl; Buffers bf;
+    pl.base = reinterpret_cast<char *>(ws);
+    plan(net, B, H, W, pl, bf);
+    if (pl.off > ws_bytes) {
+        set_error("forward: workspace of %zu bytes is too small, need %zu", ws_bytes, pl.off);
+        return PIVLFN_ERR_WORKSPACE;
+    }
+    int h[7], w[7];
+    for (int L = 1; L <= 6; ++L) { h[L] = H >> (L - 1); w[L] = W >> (L - 1); }
+    const int N2 = 2 * B;
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+    // mean subtraction + layout change (:321-323), image pyramid (:336-343)
+    RUN(launch_prep_images(img1, img2, bf.img[1], B, H, W, net->mean, st));
+    for (int L = 2; L <= 6; ++L) RUN(launch_resize_nhwc4(bf.img[L - 1], bf.img[L], N2, h[L - 1], w[L - 1], h[L], w[L], st));
+    // NetC on both frames as one batch of 2B (:325-326, Features.forward :108-116)
+    const ConvW *nc = net->netc;
+    RUN(conv(nc[0], {{bf.img[1], 4, 4}}, bf.feat[1], 32, 32, nullptr, 0, 1, N2, h[1], w[1], 1, 3, 3, st));
+    RUN(conv(nc[1], {{bf.feat[1], 32, 32}}, bf.sa, 32, 32, nullptr, 0, 1, N2, h[1], w[1], 2, 1, 1, st));
+    RUN(conv(nc[2], {{bf.sa, 32, 32}}, bf.sb, 32, 32, nullptr, 0, 1, N2, h[2], w[2], 1, 1, 1, st));
+    RUN(conv(nc[3], {{bf.sb, 32, 32}}, bf.feat[2], 32, 32, nullptr, 0, 1, N2, h[2], w[2], 1, 1, 1, st));
+    RUN(conv(nc[4], {{bf.feat[2], 32, 32}}, bf.sa, 64, 64, nullptr, 0, 1, N2, h[2], w[2], 2, 1, 1, st));
+    RUN(conv(nc[5], {{bf.sa, 64, 64}}, bf.feat[3], 64, 64, nullptr, 0, 1, N2, h[3], w[3], 1, 1, 1, st));
+    RUN(conv(nc[6], {{bf.feat[3], 64, 64}}, bf.sa, 96, 96, nullptr, 0, 1, N2, h[3], w[3], 2, 1, 1, st));
+    RUN(conv(nc[7], {{bf.sa, 96, 96}}, bf.feat[4], 96, 96, nullptr, 0, 1, N2, h[4], w[4], 1, 1, 1, st));
+    RUN(conv(nc[8], {{bf.feat[4], 96, 96}}, bf.feat[5], 128, 128, nullptr, 0, 1, N2, h[4], w[4], 2, 1, 1, st));
+    RUN(conv(nc[9], {{bf.feat[5], 128, 128}}, bf.feat[6], 192, 192, nullptr, 0, 1, N2, h[5], w[5], 2, 1, 1, st));
+    for (int L = net->lowest; L <= 2; ++L)       // NetC_ext (:353-355)
+        RUN(conv(net->ext[L], {{bf.feat[L], 32, 32}}, bf.ext[L], 64, 64, nullptr, 0, 1, N2, h[L], w[L], 1, 0, 0, st));
+
+    float *prev = nullptr, *cur = bf.flowA;
+    size_t lvoff = 0;
+    for (int L = 6; L >= net->lowest; --L) {
+        const LevelW &lw = net->lv[L];
+        const int hh = h[L], ww = w[L], k = K_LEVEL[L], cm = C_MATCH[L], cf = C_FEAT[L];
+        const size_t half = (size_t)B * hh * ww;
+        const float *f1m = L <= 2 ? bf.ext[L] : bf.feat[L];
+        const float *f2m = f1m + half * cm;
+        const float *f1raw = bf.feat[L];
+        const float *im1 = bf.img[L], *im2 = bf.img[L] + half * 4;
+        const float sc = net->scale[L];
+        const int s = L >= 4 ? 1 : 2;
+        // ---- Matching (:165-187)
+        const float *fup = nullptr;
+        if (prev) {
+            RUN(launch_dwconvT(prev, lw.upconv, bf.flow_up, B, h[L + 1], w[L + 1], 2, 4, 4, 4, st));
+            fup = bf.flow_up;
+        }
+        const bool prof = net->prof_level == L && net->ev_used + 2 <= net->ev.size();
+        if (net->prof_level == L && !prof) net->ev_dropped++;
+        if (prof) PIV_CHECK_HIP(hipEventRecord(net->ev[net->ev_used], st));
+        RUN(launch_warp_corr(f1m, f2m, fup, sc, bf.corr, B, cm, hh, ww, s, 1, true, st));
+        if (prof) { PIV_CHECK_HIP(hipEventRecord(net->ev[net->ev_used + 1], st)); net->ev_used += 2; }
+        const float *cin = bf.corr;
+        if (s == 2) {
+            RUN(launch_dwconvT(bf.corr, lw.upcorr, bf.corr_up, B, hh / 2, ww / 2, 49, 56, 56, 56, st));
+            cin = bf.corr_up;
+        }
+        RUN(conv(lw.M[0], {{cin, 56, 56}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.M[1], {{bf.t128a, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.M[2], {{bf.t64a, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.M[3], {{bf.t32a, 32, 32}}, bf.flowM, 4, 4, fup, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+        // ---- Subpixel (:209-217)
+        RUN(launch_backwarp_nhwc(f2m, bf.flowM, sc, bf.f2w, B, hh, ww, cm, st));
+        RUN(conv(lw.S[0], {{f1m, cm, cm}, {bf.f2w, cm, cm}, {bf.flowM, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.S[1], {{bf.t128a, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.S[2], {{bf.t64a, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.S[3], {{bf.t32a, 32, 32}}, bf.flowS, 4, 4, bf.flowM, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+        // ---- Regularization (:274-303); note it takes the RAW NetC feature (:361)
+        RUN(launch_flow_mean(bf.flowS, bf.partial, bf.mean, B, hh * ww, st));
+        RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, sc, bf.misc4, B, hh, ww, st));
+        const float *fr = f1raw;
+        int cfr = cf;
+        if (L < 5) {
+            RUN(conv(lw.feat, {{f1raw, cf, cf}}, bf.featR, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 0, 0, st));
+            fr = bf.featR;
+            cfr = 128;
+        }
+        RUN(conv(lw.R[0], {{bf.misc4, 4, 4}, {fr, cfr, cfr}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.R[1], {{bf.t128a, 128, 128}}, bf.t128b, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.R[2], {{bf.t128b, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.R[3], {{bf.t64a, 64, 64}}, bf.t64b, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.R[4], {{bf.t64b, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.R[5], {{bf.t32a, 32, 32}}, bf.t32b, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        const int kk = k * k, kkp = rup(kk, 4);
+        if (L < 5) {     // (k x 1) then (1 x k), no activation in between (:253-261)
+            RUN(conv(lw.dist0, {{bf.t32b, 32, 32}}, bf.d1, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, k / 2, 0, st));
+            RUN(conv(lw.dist1, {{bf.d1, kkp, kkp}}, bf.dist, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, 0, k / 2, st));
+        } else {
+            RUN(conv(lw.dist0, {{bf.t32b, 32, 32}}, bf.dist, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, k / 2, k / 2, st));
+        }
+        const bool last = L == net->lowest;
+        RUN(launch_reg_tail(bf.dist, kkp, bf.flowS, lw.wx, lw.wy, lw.bx, lw.by, k, cur, last ? flow : nullptr,
+                            net->scale[1], B, hh, ww, st));
+        if (levels) {
+            RUN(launch_flow4_to_nchw(bf.flowM, levels + lvoff, B, hh, ww, st)); lvoff += half * 2;
+            RUN(launch_flow4_to_nchw(bf.flowS, levels + lvoff, B, hh, ww, st)); lvoff += half * 2;
+            RUN(launch_flow4_to_nchw(cur, levels + lvoff, B, hh, ww, st)); lvoff += half * 2;
+        }
+        prev = cur;
+        cur = (cur == bf.flowA) ? bf.flowB : bf.flowA;
+    }
+#undef RUN
+    return PIVLFN_OK;
+}
+
+}  // namespace pivlfn

@@ -1,0 +1,136 @@
+"""GPU: pivlfn_forward (the whole level pipeline as HIP kernels) against golden flows of the reference and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import pivlfn
+import pivlfn_oracle as orc
+from pivlfn import synth
+
+pytestmark = pytest.mark.gpu
+
+# End-to-end fp32 tolerance: max-abs <= 1e-4 * max(1, max|flow|) px, and the mean
+# absolute error an order of magnitude below that.  The fp32-vs-fp64 noise floor of the reference itself on
+# these cases is 2e-6 .. 1.3e-5 px max-abs (tests/golden/pin_report.json).
+E2E_MAX = 1e-4
+E2E_MEAN = 1e-5
+
+
+def _inputs(g, tag, dev):
+    i1 = torch.from_numpy(np.stack([synth.to_input(a) for a in g[f"{tag}_img1"]])).to(dev)
+    i2 = torch.from_numpy(np.stack([synth.to_input(a) for a in g[f"{tag}_img2"]])).to(dev)
+    return i1, i2
+
+
+def _check(got, want, what):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    scale = max(1.0, np.abs(want).max())
+    err = np.abs(got - want)
+    assert err.max() <= E2E_MAX * scale, f"{what}: max-abs {err.max():.3e} vs flow scale {scale:.2f}"
+    assert err.mean() <= E2E_MEAN * scale, f"{what}: mean-abs {err.mean():.3e}"
+
+
+@pytest.fixture(scope="module")
+def nets(dev):
+    out = {}
+    for model in ("piv", "hui"):
+        n = pivlfn.Network(model=model, params=synth.generate_weights(model, 0)).to(dev)
+        n.eval()
+        out[model] = n
+    return out
+
+
+@pytest.mark.parametrize("tag", ["piv_1x64x64", "piv_2x96x160", "hui_1x64x64", "hui_2x96x160"])
+def test_forward_matches_reference_golden(tag, gold, nets, dev):
+    g = gold["e2e_cases"]
+    model = tag[:3]
+    i1, i2 = _inputs(g, tag, dev)
+    keep = i1.clone()
+    flow, levels = nets[model].forward_levels(i1, i2)
+    assert torch.equal(i1, keep)                              # inputs are not mutated
+    want = g[f"{tag}_flow"]
+    assert tuple(flow.shape) == want.shape
+    # localise first: per-level M, S, R flows (training-mode return of the reference)
+    for j, trio in enumerate(levels):
+        for name, t in zip("MSR", trio):
+            _check(t.cpu().numpy(), g[f"{tag}_lv{j}_{name}"], f"{tag} level#{j} {name}")
+    _check(flow.cpu().numpy(), want, tag)
+    again = nets[model](i1, i2)
+    assert torch.equal(again, flow)                           # run-to-run bitwise determinism
+
+
+def test_estimate_non_multiple_of_32(gold, nets, dev):
+    g = gold["e2e_cases"]
+    i1, i2 = _inputs(g, "est_piv_100x76", dev)
+    out = pivlfn.estimate(nets["piv"], i1, i2, tensor=True)
+    assert tuple(out.shape) == (1, 2, 100, 76)
+    _check(out.cpu().numpy(), g["est_piv_100x76_flow"], "estimate 100x76")
+    arr = pivlfn.estimate(nets["piv"], i1, i2, tensor=False)
+    assert arr.shape == (100, 76, 2) and arr.dtype == np.float32
+    assert np.array_equal(arr, out[0].permute(1, 2, 0).cpu().numpy())
+
+
+def test_estimate_hui_upsamples_half_resolution_flow(gold, nets, dev):
+    g = gold["e2e_cases"]
+    i1, i2 = _inputs(g, "hui_1x64x64", dev)
+    out = pivlfn.estimate(nets["hui"], i1, i2, tensor=True).cpu()
+    raw = torch.from_numpy(g["hui_1x64x64_flow"])
+    want = torch.nn.functional.interpolate(raw, size=(64, 64), mode="bilinear", align_corners=False)
+    _check(out.numpy(), want.numpy(), "estimate hui 64x64")
+
+
+def test_forward_vs_oracle_fresh_seed(nets, dev):
+    """A case that is NOT in the fixtures: 128x96, batch 2, new frames, oracle run here on the CPU."""
+    a, b = synth.particle_batch(2, 128, 96, seed=777)
+    i1, i2 = torch.from_numpy(a), torch.from_numpy(b)
+    for model in ("piv", "hui"):
+        onet = orc.make_net(model, synth.generate_weights(model, 0), corr="c")
+        with torch.no_grad():
+            want = onet.forward(i1, i2).numpy()
+        got = nets[model](i1.to(dev), i2.to(dev)).cpu().numpy()
+        _check(got, want, f"{model} 2x128x96")
+
+
+def test_batch_consistency_and_argument_errors(nets, dev):
+    a, b = synth.particle_batch(3, 64, 96, seed=31)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    full = nets["piv"](i1, i2)
+    for k in range(3):
+        one = nets["piv"](i1[k:k + 1], i2[k:k + 1])
+        assert torch.equal(one[0], full[k])                   # every pair is independent of its batch mates
+    with pytest.raises(ValueError):
+        nets["piv"](i1[:, :, :50], i2[:, :, :50])            # not a multiple of 32 -> estimate() territory
+    with pytest.raises(ValueError):
+        nets["piv"](i1, i2[:2])
+    nets["piv"].train()
+    with pytest.raises(NotImplementedError):
+        nets["piv"](i1, i2)
+    nets["piv"].eval()
+
+
+def test_reloading_weights_takes_effect(dev):
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    a, b = synth.particle_batch(1, 64, 64, seed=5)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    f0 = net(i1, i2)
+    net.load_state_dict({k: v.to(dev) for k, v in synth.generate_weights("piv", 1).items()})
+    f1 = net(i1, i2)
+    assert not torch.equal(f0, f1)
+    net.load_state_dict(synth.generate_weights("piv", 0))
+    assert torch.equal(net(i1, i2), f0)
+
+
+def test_full_size_1024_properties(nets, dev):
+    """BASELINE config #2 size: no oracle run (12 s on CPU); size-independent properties instead."""
+    a, b = synth.particle_batch(1, 1024, 1024, seed=1234)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    f = nets["piv"](i1, i2)
+    assert tuple(f.shape) == (1, 2, 1024, 1024) and torch.isfinite(f).all()
+    assert torch.equal(nets["piv"](i1, i2), f)                # deterministic
+    # translation covariance away from the borders: the top-left 512x512 crop sees the same data inside its
+    # receptive field only near the crop centre; check the crop's interior agrees to fp32 noise.
+    fc = nets["piv"](i1[:, :, :512, :512].contiguous(), i2[:, :, :512, :512].contiguous())
+    d = (fc[:, :, 192:320, 192:320] - f[:, :, 192:320, 192:320]).abs().max().item()
+    assert d < 0.5, d                                         # far inside: border effects decay, fields stay close
+    assert f.abs().max().item() > 1.0

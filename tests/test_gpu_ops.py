@@ -1,0 +1,142 @@
+"""GPU: the HIP kernels behind the C ABI against the oracle and the golden vectors (per-op)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import pivlfn
+import pivlfn_oracle as orc
+from pivlfn import _lib
+
+pytestmark = pytest.mark.gpu
+OP_TOL = 1e-5        # per-op: max-abs <= 1e-5 * max|out|  (fp32, different summation order than the CUDA kernel)
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(1e-30, np.abs(b).max()))
+
+
+def test_native_library_is_the_one_loaded(dev):
+    lib = _lib.load()
+    assert lib.pivlfn_abi_version() == 1
+    assert "libpivlfn.so" in open("/proc/self/maps").read()
+
+
+def test_correlation_golden(gold, dev):
+    g = gold["corr_cases"]
+    n = 0
+    while f"f1_{n}" in g:
+        f1, f2, s, want = g[f"f1_{n}"], g[f"f2_{n}"], int(g[f"stride_{n}"]), g[f"out_{n}"]
+        got = pivlfn.FunctionCorrelation(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev), s)
+        assert got.shape == want.shape and got.is_contiguous() and got.dtype == torch.float32
+        assert rel(got.cpu().numpy(), want) < OP_TOL, n
+        got2 = pivlfn.ModuleCorrelation()(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev), s)
+        assert torch.equal(got, got2)                # deterministic, bit for bit
+        n += 1
+    assert n >= 6
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 32, 48, 1), (2, 96, 17, 23, 1), (1, 192, 32, 32, 1), (1, 64, 64, 64, 2),
+                                   (3, 64, 31, 45, 2), (1, 128, 8, 8, 1), (1, 20, 9, 10, 1), (1, 3, 6, 7, 2),
+                                   (1, 8, 1, 1, 1), (2, 33, 5, 40, 2)])
+def test_correlation_vs_oracle(shape, dev):
+    B, C, H, W, s = shape
+    g = np.random.default_rng(hash(shape) % 2 ** 31)
+    f1 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    f2 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    want = orc.correlation_c(f1, f2, s)
+    got = pivlfn.FunctionCorrelation(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev), s).cpu().numpy()
+    assert got.shape == want.shape
+    assert rel(got, want) < OP_TOL
+
+
+def test_correlation_empty_and_errors(dev):
+    e = torch.zeros(0, 8, 4, 4, device=dev)
+    assert pivlfn.FunctionCorrelation(e, e, 1).shape == (0, 49, 4, 4)
+    a = torch.zeros(1, 8, 4, 4, device=dev)
+    with pytest.raises(AssertionError):
+        pivlfn.FunctionCorrelation(a.transpose(2, 3), a, 1)
+    with pytest.raises(ValueError):
+        pivlfn.FunctionCorrelation(a, torch.zeros(1, 8, 4, 5, device=dev), 1)
+    with pytest.raises(TypeError):
+        pivlfn.FunctionCorrelation(a.double(), a.double(), 1)
+
+
+def test_backwarp_golden(gold, dev):
+    g = gold["backwarp_cases"]
+    n = 0
+    while f"x_{n}" in g:
+        x, fl, want = g[f"x_{n}"], g[f"flow_{n}"], g[f"out_{n}"]
+        got = pivlfn.backwarp(tensorInput=torch.from_numpy(x).to(dev), tensorFlow=torch.from_numpy(fl).to(dev)).cpu().numpy()
+        # the reference goes through normalised [-1,1] coordinates; the kernel samples at x+u directly
+        assert rel(got, want) < 2e-5, n
+        assert rel(got, orc.backwarp_c(x, fl)) < 2e-6
+        n += 1
+    assert n >= 3
+
+
+def test_backwarp_out_of_range_and_identity(dev):
+    x = torch.randn(2, 5, 16, 24, device=dev)
+    assert torch.allclose(pivlfn.backwarp(x, torch.zeros(2, 2, 16, 24, device=dev)), x)
+    assert torch.all(pivlfn.backwarp(x, torch.full((2, 2, 16, 24), 1e6, device=dev)) == 0)
+    assert torch.all(pivlfn.backwarp(x, torch.full((2, 2, 16, 24), -1e9, device=dev)) == 0)
+    shift = torch.zeros(2, 2, 16, 24, device=dev)
+    shift[:, 0] = 1.0                                           # sample one pixel to the right
+    y = pivlfn.backwarp(x, shift)
+    assert torch.allclose(y[..., :-1], x[..., 1:]) and torch.all(y[..., -1] == 0)
+
+
+def _fused(f1, f2, fl, scale, s, leaky, dev, nhwc):
+    lib = _lib.load()
+    B, C, H, W = f1.shape
+    Ho, Wo = -(-H // s), -(-W // s)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    if not nhwc:
+        out = torch.empty(B, 49, Ho, Wo, device=dev)
+        _lib.check(lib.pivlfn_warp_corr_fwd(f1.data_ptr(), f2.data_ptr(), fl.data_ptr() if fl is not None else None, scale,
+                                            out.data_ptr(), B, C, H, W, s, leaky, st), "warp_corr")
+        return out
+    a = f1.permute(0, 2, 3, 1).contiguous()
+    b = f2.permute(0, 2, 3, 1).contiguous()
+    f4 = None
+    if fl is not None:
+        f4 = torch.zeros(B, H, W, 4, device=dev)
+        f4[..., :2] = fl.permute(0, 2, 3, 1)
+    out = torch.full((B, Ho, Wo, 56), float("nan"), device=dev)
+    _lib.check(lib.pivlfn_warp_corr_nhwc(a.data_ptr(), b.data_ptr(), f4.data_ptr() if f4 is not None else None, scale,
+                                         out.data_ptr(), B, C, H, W, s, leaky, st), "warp_corr_nhwc")
+    assert torch.all(out[..., 49:] == 0)                        # padding lanes are exact zeros
+    return out[..., :49].permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("shape", [(1, 64, 32, 32, 2, True), (2, 96, 24, 40, 1, True), (1, 192, 16, 16, 1, False),
+                                   (1, 128, 21, 19, 1, True), (1, 64, 30, 50, 2, True)])
+def test_fused_warp_correlation_vs_oracle_composition(shape, nhwc, dev):
+    """src/models.py:171-184: leaky_relu(corr(f1, backwarp(f2, flow*scale)))."""
+    B, C, H, W, s, warp = shape
+    g = np.random.default_rng(7 + C + H)
+    f1 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    f2 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    fl = (1.7 * g.standard_normal((B, 2, H, W))).astype(np.float32) if warp else None
+    scale = 0.625
+    f2w = orc.backwarp_c(f2, fl * np.float32(scale)) if warp else f2
+    want = orc.correlation_c(f1, f2w, s)
+    want = np.where(want >= 0, want, 0.1 * want).astype(np.float32)
+    got = _fused(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev),
+                 torch.from_numpy(fl).to(dev) if warp else None, scale, s, 1, dev, nhwc).cpu().numpy()
+    assert rel(got, want) < 2e-5
+
+
+def test_resize_bilinear_matches_torch(dev):
+    x = torch.randn(2, 4, 37, 53, device=dev)
+    for size in [(64, 64), (37, 53), (20, 100), (74, 106)]:
+        out = torch.empty(2, 4, *size, device=dev)
+        mul = (ctypes.c_float * 2)(0.5, 3.0)
+        _lib.check(_lib.load().pivlfn_resize_bilinear(x.data_ptr(), out.data_ptr(), 2, 4, 37, 53, size[0], size[1], mul,
+                                                      torch.cuda.current_stream(dev).cuda_stream), "resize")
+        want = torch.nn.functional.interpolate(x.cpu(), size=size, mode="bilinear", align_corners=False)
+        want[:, 0::2] *= 0.5
+        want[:, 1::2] *= 3.0
+        assert rel(out.cpu().numpy(), want.numpy()) < 1e-5
