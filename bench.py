@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- PIV image-pairs/s of the MI355X-native PIV-LiteFlowNet-en forward (BASELINE.json metric).
+
+One "step" = one pass of the hot path (pivlfn_forward: the whole coarse-to-fine pipeline, device-resident
+[B,3,H,W] inputs -> device-resident [B,2,H,W] flow) over one batch of synthetic particle-image pairs.
+Default workload = BASELINE.json configs[1]: PIV-LiteFlowNet-en, batch 1, 1024x1024, fp32, 1 GPU.
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own pairs (weak scaling;
+pairs are independent) and the flows are reassembled with one RCCL all-gather per step,
+issued asynchronously so it overlaps the next step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline":     the level-3 warp+correlation kernel, algorithmic bytes (24 707 072 B/pair at
+                  1024^2) / its launch duration measured live with hipEvents around that launch in every timed step;
+  "cpu_baseline": the oracle (torch CPU convs + CPU correlation) timed on this box's host cores on ONE pair
+                  of the same workload (reported baseline only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "piv_liteflownet-pytorch_amd"))
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="pairs per step per GPU (default 1 = BASELINE configs[1])")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--model", default="piv", choices=["piv", "hui"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-level", type=int, default=3, help="level whose warp+correlation launch is event-timed")
+    return ap.parse_args()
+
+
+def l3_algorithmic_bytes(B, H, W, L, C, stride):
+    """4*[C*Ho*Wo (f1 touched) + C*h*w (f2) + 2*h*w (flow) + 49*Ho*Wo (out)] per pair."""
+    h, w = H >> (L - 1), W >> (L - 1)
+    Ho, Wo = -(-h // stride), -(-w // stride)
+    flow = 2 * h * w if L < 6 else 0
+    return 4 * B * (C * Ho * Wo + C * h * w + flow + 49 * Ho * Wo)
+
+
+def host_cores():
+    """Cores this process may really use: cgroup quota if there is one, else the affinity mask, capped at 16
+    (the GPU box gives a 1-GPU job a 16-core share; 256 threads on it ran 20x slower)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("PIVLFN_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(model, size, wts, i1, i2):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pivlfn_oracle as orc
+    nthreads = host_cores()
+    torch.set_num_threads(nthreads)
+    net = orc.make_net(model, wts, corr="torch")
+    with torch.no_grad():
+        net.forward(i1[:1, :, :64, :64].contiguous(), i2[:1, :, :64, :64].contiguous())    # page in
+        t0 = time.perf_counter()
+        out = net.forward(i1[:1], i2[:1])
+        dt = time.perf_counter() - t0
+    return out, {"value": 1.0 / dt, "unit": "image-pairs/s", "cores": nthreads, "kind": "port",
+                 "sample": f"1 pair {size}x{size} fp32, oracle/pivlfn_oracle.py (torch {torch.__version__} CPU convs + "
+                           f"slicing correlation), {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+
+    import pivlfn
+    from pivlfn import synth
+
+    B, S = args.batch, args.size
+    wts = synth.generate_weights(args.model, 0)
+    a, b = synth.particle_batch(B, S, S, seed=1234 + 1000 * rank)
+    i1c, i2c = torch.from_numpy(a), torch.from_numpy(b)
+    i1, i2 = i1c.to(dev), i2c.to(dev)
+    net = pivlfn.Network(model=args.model, params=wts).to(dev).eval()
+
+    div = 2 ** (net.lowest_level - 1)
+    gathered = [torch.empty(world * B, 2, S // div, S // div, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+
+    def step(i):
+        flow = net(i1, i2)
+        if world > 1:
+            k = i & 1
+            if pending[k] is not None:
+                pending[k].wait()
+            pending[k] = dist.all_gather_into_tensor(gathered[k], flow, async_op=True)
+        return flow
+
+    def fence():
+        if world > 1:
+            for k in (0, 1):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        flow = step(i)
+    fence()
+    L = args.profile_level
+    if L:
+        net.profile_enable(L)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        flow = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    k_ms, k_n = net.profile_read() if L else (0.0, 0)
+    if L:
+        net.profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        pairs = args.steps * B * world
+        value = pairs / dt
+        C = [0, 64, 64, 64, 96, 128, 192][L] if L else 0
+        stride = 1 if L >= 4 else 2
+        roof = None
+        if L and k_n:
+            alg = l3_algorithmic_bytes(B, S, S, L, C, stride)
+            t_k = k_ms / k_n * 1e-3
+            ach = alg / t_k / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_l3_warp_corr.json")
+            if os.path.exists(pmc) and B == 1 and S == 1024 and L == 3:
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "traffic": traffic, "kernel": f"warp_corr_kernel (level {L}: C={C}, stride {stride})",
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(t_k * 1e6, 2), "launches_timed": k_n,
+                    "timer": "hipEventRecord pair around the launch in every timed step (pivlfn_profile_*)"}
+        out = {
+            "metric": "PIV image-pairs/s at 1024x1024 fp32" if S == 1024 else f"PIV image-pairs/s at {S}x{S} fp32",
+            "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{'PIV-LiteFlowNet-en' if args.model == 'piv' else 'LiteFlowNet'} forward, batch {B}/GPU, "
+                                   f"{S}x{S} synthetic PIV pair, fp32 (BASELINE configs[1])",
+                       "pairs_per_step_per_gpu": B, "weights": "generated (pivlfn.synth seed 0)",
+                       "multi_gpu": "pairs sharded over ranks, async RCCL all-gather of flows per step" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "whole_net": {"conv_tflops": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
+                          "fp32_mfma_peak_tflops": 157.3,
+                          "compute_frac": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            ref, cb = cpu_baseline(args.model, S, wts, i1c, i2c)
+            out["cpu_baseline"] = cb
+            err = float((flow[:1].cpu() - ref).abs().max())
+            out["parity_vs_oracle_max_abs_px"] = round(err, 7)
+            out["max_abs_flow_px"] = round(float(ref.abs().max()), 3)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
