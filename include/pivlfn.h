@@ -37,6 +37,9 @@ typedef struct {
 const char *pivlfn_last_error(void);
 int         pivlfn_abi_version(void);
 
+/* Benchmark-only tuning knobs (kernel variant selection for in-process A/B timing); defaults are the shipped path. */
+int         pivlfn_tune(int knob, int value);
+
 /* ---- custom op: replaces _FunctionCorrelation.forward, src/correlation.py:287-344 (+ kernels :9-104)
  * first, second: NCHW [B,C,H,W]; out: NCHW [B,49,ceil(H/stride),ceil(W/stride)];
  * out[b,7(dy+3)+(dx+3),y,x] = (1/C) sum_c first[b,c,s*y,s*x] * second[b,c,s*(y+dy),s*(x+dx)], zeros outside. */

@@ -7,6 +7,7 @@ struct pivlfn_net;
 namespace pivlfn {
 
 static thread_local char g_err[512] = "";
+int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 void set_error(const char *fmt, ...)
 {
@@ -33,6 +34,13 @@ extern "C" {
 
 const char *pivlfn_last_error(void) { return g_err; }
 int pivlfn_abi_version(void) { return 1; }
+
+int pivlfn_tune(int knob, int value)
+{
+    if (knob < 0 || knob >= 8) { set_error("tune: knob %d out of range", knob); return PIVLFN_ERR_ARG; }
+    g_knob[knob] = value;
+    return PIVLFN_OK;
+}
 
 int pivlfn_corr_fwd(const float *first, const float *second, float *out, int B, int C, int H, int W, int stride, void *stream)
 {

@@ -10,6 +10,9 @@ namespace pivlfn {
 
 void set_error(const char *fmt, ...);
 
+// Tuning knobs for A/B measurements (pivlfn_tune): 0 = warp_corr variant, 1 = conv variant.
+extern int g_knob[8];
+
 #define PIV_CHECK_HIP(expr)                                                                  \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \

@@ -18,6 +18,7 @@
 //     floats -> conflict-free), 13 private accumulators, no cross-lane reduction at all;
 //   * results are transposed through LDS so the [B,Ho,Wo,56] store is made of whole 16-byte lanes;
 //   * workgroup ids are remapped so every XCD owns a contiguous band of tiles (halo re-reads hit its L2).
+#include <cstdlib>
 #include "common.h"
 
 namespace pivlfn {
@@ -34,6 +35,7 @@ struct WcParams {
     float *out;
     float scale;
     int B, C, H, W, s, Ho, Wo, leaky;
+    int dbg;      // ablation mask for tools/bench_ops.py (0 in production): 1 skip dot products, 2 skip gathers, 4 skip store, 8 exit at entry
 };
 
 
@@ -186,6 +188,599 @@ __global__ __launch_bounds__(256) void warp_corr_kernel(const WcParams p)
     }
 }
 
+
+// ---- channels-last kernel (the one pivlfn_forward launches) ---------------------------------------------------------
+// v2 structure, built for memory-level parallelism (a tile is ~200 KB of gathers behind a dependent flow read):
+//   phase 0  every thread issues its share of the f1 tile loads (independent of everything else);
+//   phase A  196 threads read the flow at their position and write the 4 bilinear taps (pixel index or -1, weight)
+//            into an LDS tap table -- ONE dependent round trip per tile instead of one per gathered vector;
+//   phase B  all threads gather (position, 16-byte channel quad) items: tap table from LDS, four unconditional
+//            16-byte loads (index clamped, value masked afterwards), unrolled by UNR so >= 16 loads per thread are in
+//            flight; blended vectors go to LDS;
+//   phase C  lane = output pixel, wave = displacement group, operands streamed with ds_read_b128 (as v1);
+//   NW waves per workgroup (8 -> two waves per SIMD, so VALU issue and LDS latency overlap).
+template <int CC, int NW, bool HASFLOW>
+__global__ __launch_bounds__(NW * 64) void warp_corr_nhwc_kernel(const WcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = NW * 64;
+    constexpr int PP = CC + 4;
+    constexpr int Q = CC / 4;
+    constexpr int ND = (49 + NW - 1) / NW;   // displacements per thread
+    float *f2w = smem;                       // [NPOS][PP]
+    float *f1t = f2w + NPOS * PP;            // [64][PP]
+    int *tapo = reinterpret_cast<int *>(f1t + 64 * PP);   // [4][NPOS]
+    float *tapw = reinterpret_cast<float *>(tapo + 4 * NPOS);
+
+    const int tiles_x = (p.Wo + TO - 1) / TO, tiles_y = (p.Ho + TO - 1) / TO;
+    const int nblk = tiles_x * tiles_y * p.B;
+    int bid = xcd_remap(blockIdx.x, nblk);
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int ox0 = tx * TO, oy0 = ty * TO;
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    const int ppx = lane & 7, ppy = lane >> 3;
+    const size_t img = (size_t)p.H * p.W;
+    const float *f1img = p.f1 + (size_t)b * img * p.C;
+    const float *f2img = p.f2 + (size_t)b * img * p.C;
+
+    // phase A: tap table (shared by all channel chunks)
+    if (tid < NPOS) {
+        const int iy = (oy0 + tid / TP - 3) * p.s, ix = (ox0 + tid % TP - 3) * p.s;
+        Taps t;
+        t.o00 = t.o01 = t.o10 = t.o11 = -1;
+        t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            if (HASFLOW) {
+                const float2 uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)iy * p.W + ix) * 4);
+                t = make_taps((float)ix + uv.x * p.scale, (float)iy + uv.y * p.scale, p.H, p.W);
+            } else {
+                t.o00 = iy * p.W + ix;
+                t.w00 = 1.f;
+            }
+        }
+        tapo[0 * NPOS + tid] = t.o00; tapo[1 * NPOS + tid] = t.o01; tapo[2 * NPOS + tid] = t.o10; tapo[3 * NPOS + tid] = t.o11;
+        tapw[0 * NPOS + tid] = t.w00; tapw[1 * NPOS + tid] = t.w01; tapw[2 * NPOS + tid] = t.w10; tapw[3 * NPOS + tid] = t.w11;
+    }
+
+    float acc[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) acc[k] = 0.f;
+    constexpr int F1_PER = (64 * Q + NT - 1) / NT;
+    constexpr int NITEM = NPOS * Q;
+    constexpr int UNR = HASFLOW ? 4 : 8;
+
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+        // phase 0: f1 tile -> registers (stored to LDS after the barrier below)
+        f32x4 f1r[F1_PER];
+#pragma unroll
+        for (int i = 0; i < F1_PER; ++i) {
+            const int idx = tid + i * NT;
+            const int pp = idx / Q, q = idx - pp * Q;
+            const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < 64 * Q && oy < p.Ho && ox < p.Wo)
+                v = *reinterpret_cast<const f32x4 *>(f1img + ((size_t)(oy * p.s) * p.W + ox * p.s) * p.C + c0 + 4 * q);
+            f1r[i] = v;
+        }
+        __syncthreads();        // tap table visible (first chunk) / previous chunk's compute finished (later chunks)
+        // phase B: gather + blend
+        const float *f2c = f2img + c0;
+        for (int base = 0; base < NITEM; base += NT * UNR) {
+            f32x4 x[UNR][HASFLOW ? 4 : 1];
+            float w[UNR][HASFLOW ? 4 : 1];
+            int o[UNR][HASFLOW ? 4 : 1];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                int idx = base + u * NT + tid;
+                idx = idx < NITEM ? idx : NITEM - 1;
+                const int pos = idx / Q, q = idx - pos * Q;
+#pragma unroll
+                for (int k = 0; k < (HASFLOW ? 4 : 1); ++k) {
+                    o[u][k] = tapo[k * NPOS + pos];
+                    w[u][k] = tapw[k * NPOS + pos];
+                    const int oc = o[u][k] < 0 ? 0 : o[u][k];
+                    x[u][k] = *reinterpret_cast<const f32x4 *>(f2c + (size_t)oc * p.C + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + u * NT + tid;
+                if (idx < NITEM) {
+                    const int pos = idx / Q, q = idx - pos * Q;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < (HASFLOW ? 4 : 1); ++k)
+                        if (o[u][k] >= 0) v += w[u][k] * x[u][k];
+                    *reinterpret_cast<f32x4 *>(f2w + pos * PP + 4 * q) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < F1_PER; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < 64 * Q) {
+                const int pp = idx / Q, q = idx - pp * Q;
+                *reinterpret_cast<f32x4 *>(f1t + pp * PP + 4 * q) = f1r[i];
+            }
+        }
+        __syncthreads();
+
+        // phase C
+        f32x4 a[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) a[q] = *reinterpret_cast<const f32x4 *>(f1t + lane * PP + 4 * q);
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int d = grp + NW * k;
+            if (d < 49) {
+                const int dy = d / 7, dx = d - dy * 7;
+                const float *src = f2w + ((ppy + dy) * TP + ppx + dx) * PP;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < Q; q += 2) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + 4 * q);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(src + 4 * q + 4);
+                    s0 = fmaf(a[q][0], v0[0], s0); s0 = fmaf(a[q][1], v0[1], s0);
+                    s0 = fmaf(a[q][2], v0[2], s0); s0 = fmaf(a[q][3], v0[3], s0);
+                    s1 = fmaf(a[q + 1][0], v1[0], s1); s1 = fmaf(a[q + 1][1], v1[1], s1);
+                    s1 = fmaf(a[q + 1][2], v1[2], s1); s1 = fmaf(a[q + 1][3], v1[3], s1);
+                }
+                acc[k] += s0 + s1;
+            }
+        }
+    }
+
+    __syncthreads();
+    float *ost = smem;                       // [64][56], exact zeros in lanes 49..55
+    const float cf = (float)p.C;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int d = grp + NW * k;
+        if (d < 49) {
+            float v = acc[k] / cf;
+            if (p.leaky) v = lrelu01(v);
+            ost[lane * OUTC + d] = v;
+        }
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * (OUTC / 4); idx += NT) {
+        const int pp = idx / (OUTC / 4), q = idx - pp * (OUTC / 4);
+        const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
+        if (oy < p.Ho && ox < p.Wo)
+            *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) =
+                *reinterpret_cast<const f32x4 *>(ost + pp * OUTC + 4 * q);
+    }
+}
+
+template <int CC, int NW, bool HASFLOW>
+static int launch_wc2(const WcParams &p, hipStream_t st)
+{
+    const size_t lds = ((size_t)(NPOS + 64) * (CC + 4) + 8 * NPOS) * sizeof(float);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_nhwc_kernel<CC, NW, HASFLOW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
+    hipLaunchKernelGGL((warp_corr_nhwc_kernel<CC, NW, HASFLOW>), dim3(nblk), dim3(NW * 64), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+
+// ---- v3: 32-channel chunks, double-buffered LDS, gathers of chunk k+1 in flight while chunk k is consumed -------------
+// 512 threads (two waves per SIMD).  All gathers are buffer loads through a per-image descriptor: one 32-bit byte
+// offset per load, and a tap that falls outside the image is encoded as an offset beyond num_records, for which the
+// hardware range check returns zeros -- the zero padding of grid_sample / of the correlation costs no instruction.
+// Per chunk a thread owns 3 gather items (position, 16-byte quad) (+ a 4th for the first 32 threads: 196*8 = 3*512+32)
+// and one f1 item.  Chunk k+1's loads are issued right after chunk k's registers have been blended into LDS, so they
+// are in flight during chunk k's dot products.
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+constexpr unsigned OOB = 0x80000000u;
+
+// LDS image of the warped tile: position-major 128-byte vectors (32 channels), quad q of position (r, c) stored at quad
+// slot q ^ g, g = 2*(r&3) + ((c>>1)&1).  With lane = output pixel, every 16-lane group of a ds_read_b128 then covers
+// all 16 slots of the 256-byte bank row for any displacement (dy, dx): conflict-free without padding.
+__device__ __forceinline__ int swz_pos(int pos)
+{
+    const int r = pos / TP, c = pos - r * TP;
+    return ((r & 3) * 2 + ((c >> 1) & 1)) & 7;
+}
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+}
+
+template <bool HASFLOW>
+__global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PP = 32, Q = 8;                  // unpadded 128-byte vectors, 16-byte quads XOR-swizzled (below)
+    constexpr int BUF = (NPOS + 64) * PP;          // floats per (f2w, f1) buffer
+    constexpr int NT = HASFLOW ? 4 : 1;
+    constexpr int REM = NPOS * Q - 3 * 512;        // 32 items left for a 4th slot
+    unsigned *tapo = reinterpret_cast<unsigned *>(smem + 2 * BUF);     // [4][NPOS] byte offsets (OOB = outside)
+    float *tapw = reinterpret_cast<float *>(tapo + 4 * NPOS);          // [4][NPOS]
+
+    const int tiles_x = (p.Wo + TO - 1) / TO, tiles_y = (p.Ho + TO - 1) / TO;
+    const int nblk = tiles_x * tiles_y * p.B;
+    int bid = xcd_remap(blockIdx.x, nblk);
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int ox0 = tx * TO, oy0 = ty * TO;
+    if (p.dbg & 8) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform
+    const size_t img = (size_t)p.H * p.W;
+    const unsigned img_bytes = (unsigned)(img * p.C * sizeof(float));
+    const unsigned pix_bytes = (unsigned)p.C * 4u;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
+
+    if (tid < NPOS) {
+        const int iy = (oy0 + tid / TP - 3) * p.s, ix = (ox0 + tid % TP - 3) * p.s;
+        unsigned o0 = OOB, o1 = OOB, o2 = OOB, o3 = OOB;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            if (HASFLOW) {
+                const float2 uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)iy * p.W + ix) * 4);
+                const Taps t = make_taps((float)ix + uv.x * p.scale, (float)iy + uv.y * p.scale, p.H, p.W);
+                o0 = t.o00 < 0 ? OOB : (unsigned)t.o00 * pix_bytes; o1 = t.o01 < 0 ? OOB : (unsigned)t.o01 * pix_bytes;
+                o2 = t.o10 < 0 ? OOB : (unsigned)t.o10 * pix_bytes; o3 = t.o11 < 0 ? OOB : (unsigned)t.o11 * pix_bytes;
+                w0 = t.w00; w1 = t.w01; w2 = t.w10; w3 = t.w11;
+            } else {
+                o0 = (unsigned)(iy * p.W + ix) * pix_bytes;
+                w0 = 1.f;
+            }
+        }
+        tapo[0 * NPOS + tid] = o0; tapo[1 * NPOS + tid] = o1; tapo[2 * NPOS + tid] = o2; tapo[3 * NPOS + tid] = o3;
+        tapw[0 * NPOS + tid] = w0; tapw[1 * NPOS + tid] = w1; tapw[2 * NPOS + tid] = w2; tapw[3 * NPOS + tid] = w3;
+    }
+    // this thread's items: 3 full slots + the remainder slot + one f1 quad
+    const int q8 = tid & 7;                        // quad within the 32-channel chunk (same in every slot: 512 % 8 == 0)
+    const int pos0 = tid >> 3;                     // slot u covers position pos0 + 64*u
+    const int fpp = tid >> 3;                      // f1 pixel of this thread
+    const int foy = oy0 + (fpp >> 3), fox = ox0 + (fpp & 7);
+    const unsigned f1off = (foy < p.Ho && fox < p.Wo) ? (unsigned)((foy * p.s) * p.W + fox * p.s) * pix_bytes + 16u * q8 : OOB;
+    __syncthreads();
+    // remainder items (positions 192..195 x 8 quads = REM items): thread t < 4*REM owns tap (t&3) of item (t>>2)
+    const int rem_pos = 192 + (tid >> 5), rem_q = (tid >> 2) & 7;
+    const unsigned rem_off = tid < 4 * REM ? tapo[(tid & 3) * NPOS + rem_pos] + 16u * rem_q : OOB;
+    const float rem_w = tid < 4 * REM ? tapw[(tid & 3) * NPOS + rem_pos] : 0.f;
+
+    float acc[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] = 0.f;
+    const int nch = p.C >> 5;
+    f32x4 xa[3][NT];                  // gathered taps of this thread's three (position, quad) items
+    f32x4 fa, ra;                     // f1 quad; remainder item (one TAP of one of the 32 left-over items, threads < 128)
+
+#define WC3_ISSUE(X, XF, XR, CB)                                                                  \
+    do {                                                                                          \
+        const unsigned cb_ = (unsigned)(CB)*128u + 16u * q8;                                      \
+        if (p.dbg & 2) {   /* ablation: no memory traffic */                                      \
+            _Pragma("unroll") for (int u = 0; u < 3; ++u)                                         \
+                _Pragma("unroll") for (int k = 0; k < NT; ++k) X[u][k] = f32x4{1.f, 2.f, 3.f, 4.f}; \
+            XR = f32x4{1.f, 2.f, 3.f, 4.f};                                                       \
+            XF = f32x4{1.f, 1.f, 1.f, 1.f};                                                       \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int u = 0; u < 3; ++u)                                         \
+                _Pragma("unroll") for (int k = 0; k < NT; ++k)                                    \
+                    X[u][k] = bload(rs2, tapo[k * NPOS + pos0 + 64 * u] + cb_);                   \
+            XR = bload(rs2, rem_off + (unsigned)(CB)*128u);                                       \
+            XF = bload(rs1, f1off + (unsigned)(CB)*128u);                                         \
+        }                                                                                         \
+    } while (0)
+
+#define WC3_COMMIT(X, XF, XR, F2W, F1T)                                                             \
+    do {                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                           \
+            const int pos = pos0 + 64 * u;                                                        \
+            f32x4 v = tapw[pos] * X[u][0];                                                        \
+            _Pragma("unroll") for (int k = 1; k < NT; ++k) v += tapw[k * NPOS + pos] * X[u][k];   \
+            *reinterpret_cast<f32x4 *>(F2W + pos * PP + 4 * (q8 ^ swz_pos(pos))) = v;             \
+        }                                                                                         \
+        if (grp < 2) {      /* waves 0,1: the 32 left-over items, one tap per lane, summed over each lane quad */ \
+            f32x4 v = rem_w * XR;                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                       \
+                v[e] += __shfl_xor(v[e], 1);                                                      \
+                v[e] += __shfl_xor(v[e], 2);                                                      \
+            }                                                                                     \
+            if ((tid & 3) == 0) *reinterpret_cast<f32x4 *>(F2W + rem_pos * PP + 4 * (rem_q ^ swz_pos(rem_pos))) = v; \
+        }                                                                                         \
+        *reinterpret_cast<f32x4 *>(F1T + fpp * PP + 4 * (q8 ^ ((fpp >> 1) & 7))) = XF;            \
+    } while (0)
+
+#define WC3_DOTS(F2W, F1T)                                                                        \
+    do {                                                                                          \
+        int lane_l_ = lane;                                                                       \
+        asm volatile("" : "+v"(lane_l_));   /* opaque per chunk: no hoisting of the LDS read addresses out of the loop */ \
+        const int ppx = lane_l_ & 7, ppy = lane_l_ >> 3;                                          \
+        const char *fb_ = reinterpret_cast<const char *>(F2W);                                    \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {      /* two 16-channel halves: 16 f1 registers live */ \
+            f32x4 a[4];                                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                         \
+                a[q] = *reinterpret_cast<const f32x4 *>(F1T + lane * PP + 4 * ((4 * hf + q) ^ ((lane >> 1) & 7))); \
+            _Pragma("unroll") for (int k = 0; k < 7; ++k) {                                       \
+                const int d = grp + 8 * k;               /* wave-uniform (grp is an SGPR) */      \
+                if (k < 6 || grp == 0) {                 /* d < 49: only wave 0 has a 7th */      \
+                    const int dy = d / 7, dx = d - dy * 7;                                        \
+                    const int r = ppy + dy, cx = ppx + dx;                                        \
+                    const unsigned sb = (unsigned)(r * TP + cx) * 128u | (unsigned)(((r & 3) * 2 + ((cx >> 1) & 1)) << 4); \
+                    float s0 = 0.f;                                                               \
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                               \
+                        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(fb_ + (sb ^ (unsigned)(16 * (4 * hf + q)))); \
+                        s0 = fmaf(a[q][0], v0[0], s0); s0 = fmaf(a[q][1], v0[1], s0);             \
+                        s0 = fmaf(a[q][2], v0[2], s0); s0 = fmaf(a[q][3], v0[3], s0);             \
+                    }                                                                             \
+                    acc[k] += s0;                                                                 \
+                    asm volatile("" : "+v"(acc[k]));  /* materialise here: the FMA chains must not sink below all the reads */ \
+                }                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);    /* keep each displacement's LDS reads next to their FMAs */ \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
+    WC3_ISSUE(xa, fa, ra, 0);
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        float *buf = smem + (c & 1) * BUF;
+        WC3_COMMIT(xa, fa, ra, buf, (buf + NPOS * PP));            // waits for chunk c's loads, blends, writes LDS buffer c&1
+        if (c + 1 < nch) WC3_ISSUE(xa, fa, ra, c + 1);             // next chunk in flight during the dot products below
+        __syncthreads();     // buffer c&1 complete; every wave is past the dot products on buffer (c+1)&1
+        if (!(p.dbg & 1)) WC3_DOTS(buf, (buf + NPOS * PP));
+    }
+#undef WC3_COMMIT
+#undef WC3_DOTS
+#undef WC3_ISSUE
+
+    __syncthreads();
+    float *ost = smem;
+    const float cf = (float)p.C;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int d = grp + 8 * k;
+        if (d < 49) {
+            float v = acc[k] / cf;
+            if (p.leaky) v = lrelu01(v);
+            ost[lane * OUTC + d] = v;
+        }
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * (OUTC / 4); idx += 512) {
+        const int pp = idx / (OUTC / 4), q = idx - pp * (OUTC / 4);
+        const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
+        if (oy < p.Ho && ox < p.Wo && !(p.dbg & 4))
+            *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) =
+                *reinterpret_cast<const f32x4 *>(ost + pp * OUTC + 4 * q);
+    }
+}
+
+template <bool HASFLOW>
+static int launch_wc3(const WcParams &p, hipStream_t st)
+{
+    const size_t lds = ((size_t)2 * (NPOS + 64) * 32 + 8 * NPOS) * sizeof(float);
+    PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
+    static bool attr = false;
+    if (!attr) {
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_v3_kernel<HASFLOW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
+    hipLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW>), dim3(nblk), dim3(512), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+
+// ---- v4: one whole CU per tile (1024 threads = 16 waves), 64-channel vectors, every gather of the tile in flight at once --
+// Built for the latency-bound case the project's roofline target names (level 3 of a 1024x1024 pair: 256 tiles = one
+// per CU): two dependent memory round trips (flow -> taps, taps -> gathers), three barriers, and each phase spread over
+// 16 waves.  Per 64-channel chunk a thread owns 3 (position, 16-byte quad) items = 12 tap loads, one tap of a left-over
+// item (positions 192..195) and one f1 quad: 14 buffer loads in flight per thread, 14 KiB per wave, 224 KiB per CU.
+// LDS image: position-major 256-byte vectors, quad q of tile position (r, c) at quad slot q ^ (4*(r&3) + (c&3)); with
+// lane = output pixel every 16-lane group of a ds_read_b128 covers all 16 slots of the 256-byte bank row for any (dy, dx).
+__device__ __forceinline__ int swz16(int pos)
+{
+    const int r = pos / TP, c = pos - r * TP;
+    return ((r & 3) << 2) | (c & 3);
+}
+
+template <bool HASFLOW>
+__global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PP = 64;                         // floats per position vector
+    constexpr int NT = HASFLOW ? 4 : 1;
+    float *f2w = smem;                             // [NPOS][64]
+    float *f1t = smem + NPOS * PP;                 // [64][64]
+    unsigned *tapo = reinterpret_cast<unsigned *>(f1t + 64 * PP);      // [4][NPOS] byte offsets (OOB = outside)
+    float *tapw = reinterpret_cast<float *>(tapo + 4 * NPOS);          // [4][NPOS]
+
+    const int tiles_x = (p.Wo + TO - 1) / TO, tiles_y = (p.Ho + TO - 1) / TO;
+    const int nblk = tiles_x * tiles_y * p.B;
+    int bid = xcd_remap(blockIdx.x, nblk);
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int ox0 = tx * TO, oy0 = ty * TO;
+    if (p.dbg & 8) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id 0..15, provably uniform
+    const size_t img = (size_t)p.H * p.W;
+    const unsigned img_bytes = (unsigned)(img * p.C * sizeof(float));
+    const unsigned pix_bytes = (unsigned)p.C * 4u;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
+
+    // f1 quad of this thread (independent of the flow: issued first)
+    const int q16 = tid & 15, pq = tid >> 4;        // pq: f1 pixel / first gather position of this thread
+    const int foy = oy0 + (pq >> 3), fox = ox0 + (pq & 7);
+    const unsigned f1off = (foy < p.Ho && fox < p.Wo) ? (unsigned)((foy * p.s) * p.W + fox * p.s) * pix_bytes + 16u * q16 : OOB;
+    f32x4 xf = bload(rs1, f1off);
+
+    if (tid < NPOS) {
+        const int iy = (oy0 + tid / TP - 3) * p.s, ix = (ox0 + tid % TP - 3) * p.s;
+        unsigned o0 = OOB, o1 = OOB, o2 = OOB, o3 = OOB;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            if (HASFLOW) {
+                const float2 uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)iy * p.W + ix) * 4);
+                const Taps t = make_taps((float)ix + uv.x * p.scale, (float)iy + uv.y * p.scale, p.H, p.W);
+                o0 = t.o00 < 0 ? OOB : (unsigned)t.o00 * pix_bytes; o1 = t.o01 < 0 ? OOB : (unsigned)t.o01 * pix_bytes;
+                o2 = t.o10 < 0 ? OOB : (unsigned)t.o10 * pix_bytes; o3 = t.o11 < 0 ? OOB : (unsigned)t.o11 * pix_bytes;
+                w0 = t.w00; w1 = t.w01; w2 = t.w10; w3 = t.w11;
+            } else {
+                o0 = (unsigned)(iy * p.W + ix) * pix_bytes;
+                w0 = 1.f;
+            }
+        }
+        tapo[0 * NPOS + tid] = o0; tapo[1 * NPOS + tid] = o1; tapo[2 * NPOS + tid] = o2; tapo[3 * NPOS + tid] = o3;
+        tapw[0 * NPOS + tid] = w0; tapw[1 * NPOS + tid] = w1; tapw[2 * NPOS + tid] = w2; tapw[3 * NPOS + tid] = w3;
+    }
+    __syncthreads();
+    // left-over items: positions 192..195 x 16 quads = 64 items; thread t < 256 owns tap (t&3) of item (t>>2)
+    const int rem_pos = 192 + (tid >> 6), rem_q = (tid >> 2) & 15;
+    const unsigned rem_off = tid < 256 ? tapo[(tid & 3) * NPOS + rem_pos] + 16u * rem_q : OOB;
+    const float rem_w = tid < 256 ? tapw[(tid & 3) * NPOS + rem_pos] : 0.f;
+
+    float acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+
+#pragma unroll 1
+    for (int c0 = 0; c0 < p.C; c0 += 64) {
+        const unsigned cb = (unsigned)c0 * 4u + 16u * q16;
+        f32x4 x[3][NT], xr;
+        if (p.dbg & 2) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) x[u][k] = f32x4{1.f, 2.f, 3.f, 4.f};
+            xr = f32x4{1.f, 2.f, 3.f, 4.f};
+        } else {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) x[u][k] = bload(rs2, tapo[k * NPOS + pq + 64 * u] + cb);
+            xr = bload(rs2, rem_off + (unsigned)c0 * 4u);
+            if (c0) xf = bload(rs1, f1off + (unsigned)c0 * 4u);
+        }
+        if (c0) __syncthreads();          // previous chunk's dot products are done with the LDS image
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int pos = pq + 64 * u;
+            f32x4 v = tapw[pos] * x[u][0];
+#pragma unroll
+            for (int k = 1; k < NT; ++k) v += tapw[k * NPOS + pos] * x[u][k];
+            *reinterpret_cast<f32x4 *>(f2w + pos * PP + 4 * (q16 ^ swz16(pos))) = v;
+        }
+        if (grp < 4) {                    // waves 0..3: the 64 left-over items, one tap per lane, summed over each lane quad
+            f32x4 v = rem_w * xr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += __shfl_xor(v[e], 1);
+                v[e] += __shfl_xor(v[e], 2);
+            }
+            if ((tid & 3) == 0) *reinterpret_cast<f32x4 *>(f2w + rem_pos * PP + 4 * (rem_q ^ swz16(rem_pos))) = v;
+        }
+        *reinterpret_cast<f32x4 *>(f1t + pq * PP + 4 * (q16 ^ (pq & 15))) = xf;
+        __syncthreads();
+
+        if (!(p.dbg & 1)) {
+            int lane_l = lane;
+            asm volatile("" : "+v"(lane_l));      // opaque per chunk: keeps the 64 LDS read addresses from being hoisted out of the loop
+            const int ppx = lane_l & 7, ppy = lane_l >> 3;
+            const char *fb = reinterpret_cast<const char *>(f2w);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {          // four 16-channel quarters: 16 f1 registers live at a time
+                f32x4 a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    a[q] = *reinterpret_cast<const f32x4 *>(f1t + lane * PP + 4 * ((4 * h + q) ^ (lane & 15)));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int d = grp + 16 * k;        // wave-uniform
+                    if (k < 3 || grp == 0) {           // d < 49: only wave 0 has a 4th displacement
+                        const int dy = d / 7, dx = d - dy * 7;
+                        const int r = ppy + dy, cx = ppx + dx;
+                        const unsigned sb = (unsigned)(r * TP + cx) * 256u | (unsigned)((((r & 3) << 2) | (cx & 3)) << 4);
+                        float s0 = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(fb + (sb ^ (unsigned)(16 * (4 * h + q))));
+                            s0 = fmaf(a[q][0], v0[0], s0); s0 = fmaf(a[q][1], v0[1], s0);
+                            s0 = fmaf(a[q][2], v0[2], s0); s0 = fmaf(a[q][3], v0[3], s0);
+                        }
+                        acc[k] += s0;
+                        asm volatile("" : "+v"(acc[k]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    float *ost = smem;                           // [64][56], exact zeros in lanes 49..55
+    const float cf = (float)p.C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = grp + 16 * k;
+        if (k < 3 || grp == 0) {
+            float v = acc[k] / cf;
+            if (p.leaky) v = lrelu01(v);
+            ost[lane * OUTC + d] = v;
+        }
+    }
+    if (grp == 1) {
+#pragma unroll
+        for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
+    }
+    __syncthreads();
+    if (tid < 64 * (OUTC / 4) && !(p.dbg & 4)) {
+        const int pp = tid / (OUTC / 4), q = tid - pp * (OUTC / 4);
+        const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
+        if (oy < p.Ho && ox < p.Wo)
+            *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) =
+                *reinterpret_cast<const f32x4 *>(ost + pp * OUTC + 4 * q);
+    }
+}
+
+template <bool HASFLOW>
+static int launch_wc4(const WcParams &p, hipStream_t st)
+{
+    const size_t lds = ((size_t)(NPOS + 64) * 64 + 8 * NPOS) * sizeof(float);
+    PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
+    static bool attr = false;
+    if (!attr) {
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_v4_kernel<HASFLOW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
+    hipLaunchKernelGGL((warp_corr_v4_kernel<HASFLOW>), dim3(nblk), dim3(1024), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
 template <int CC, bool NHWC>
 static int launch_wc(const WcParams &p, hipStream_t st)
 {
@@ -202,17 +797,35 @@ static int launch_wc(const WcParams &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
+static int wc_variant() { return g_knob[0]; }
+
 int launch_warp_corr(const float *f1, const float *f2, const float *flow, float flow_scale, float *out,
                      int B, int C, int H, int W, int stride, int leaky, bool nhwc, hipStream_t st)
 {
     PIV_REQUIRE(f1 && f2 && out, "warp_corr: null pointer");
     PIV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "warp_corr: empty shape B=%d C=%d H=%d W=%d", B, C, H, W);
     PIV_REQUIRE(stride >= 1 && stride <= 4, "warp_corr: stride=%d unsupported", stride);
-    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky};
+    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, g_knob[2]};
     if (nhwc) {
         PIV_REQUIRE(C % 32 == 0, "warp_corr (channels-last): C=%d must be a multiple of 32", C);
-        if (C % 64 == 0) return launch_wc<64, true>(p, st);
-        return launch_wc<32, true>(p, st);
+        const int variant = wc_variant();
+        if (variant == 1) {                       // v1 kernel, kept for A/B measurements (PIVLFN_WC_VARIANT=1)
+            if (C % 64 == 0) return launch_wc<64, true>(p, st);
+            return launch_wc<32, true>(p, st);
+        }
+        // Shipped policy: up to two tiles per CU the launch is latency-bound -> v4 (a whole CU per tile, needs C % 64 == 0);
+        // beyond that throughput-bound -> v3 (512 threads, 128 VGPRs: two workgroups per CU overlap each other's phases).
+        const long tiles = (long)cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * B;
+        if ((variant == 0 && C % 64 == 0 && tiles <= 512) || (variant == 5 && C % 64 == 0))
+            return flow ? launch_wc4<true>(p, st) : launch_wc4<false>(p, st);
+        if (variant == 0 || variant == 4 || variant == 5) return flow ? launch_wc3<true>(p, st) : launch_wc3<false>(p, st);
+        if (variant == 2) {                       // v2 with 4 waves
+            if (C % 64 == 0) return flow ? launch_wc2<64, 4, true>(p, st) : launch_wc2<64, 4, false>(p, st);
+            return flow ? launch_wc2<32, 4, true>(p, st) : launch_wc2<32, 4, false>(p, st);
+        }
+        // variant 3: v2 with 8 waves
+        if (C % 64 == 0) return flow ? launch_wc2<64, 8, true>(p, st) : launch_wc2<64, 8, false>(p, st);
+        return flow ? launch_wc2<32, 8, true>(p, st) : launch_wc2<32, 8, false>(p, st);
     }
     if (C % 64 == 0) return launch_wc<64, false>(p, st);
     return launch_wc<32, false>(p, st);   // any C: the last chunk is zero-filled past C

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""A/B micro-benchmarks of single kernels at the shapes of the 1024x1024 PIV forward (one process, interleaved rounds).
+
+  python tools/bench_ops.py warp_corr [--batch 1] [--variants 1,2,0]
+Times N back-to-back launches between two events on the current stream (so each figure includes one ~1.5 us
+kernel boundary) and checks that all variants agree.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "piv_liteflownet-pytorch_amd"))
+from pivlfn import _lib  # noqa: E402
+
+LEVELS = {1: (64, 1024, 2), 2: (64, 512, 2), 3: (64, 256, 2), 4: (96, 128, 1), 5: (128, 64, 1), 6: (192, 32, 1)}
+
+
+def time_it(fn, n=50, rounds=5):
+    ts = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / n * 1e3)
+    return min(ts), sorted(ts)[len(ts) // 2]
+
+
+def bench_warp_corr(args):
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    B = args.batch
+    variants = [int(v) for v in args.variants.split(",")]
+    for L in [int(x) for x in args.levels.split(",")]:
+        C, n, s = LEVELS[L]
+        f1 = torch.randn(B, n, n, C, device=dev)
+        f2 = torch.randn(B, n, n, C, device=dev)
+        fl = torch.zeros(B, n, n, 4, device=dev)
+        fl[..., :2] = torch.randn(B, n, n, 2, device=dev) * 0.8
+        no = -(-n // s)
+        flow_ptr = fl.data_ptr() if L < 6 else None
+        outs = {}
+        alg = 4 * B * (C * no * no + C * n * n + (2 * n * n if L < 6 else 0) + 49 * no * no)
+        for v in variants:
+            out = torch.empty(B, no, no, 56, device=dev)
+            outs[v] = out
+
+            def fn(v=v, out=out):
+                lib.pivlfn_tune(0, v)
+                _lib.check(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), flow_ptr, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
+            tmin, tmed = time_it(fn)
+            print(f"L{L} B={B} C={C} {n}x{n} s={s} variant {v}: min {tmin:8.2f} us  med {tmed:8.2f} us   "
+                  f"{alg / tmin / 1e3:8.1f} GB/s algorithmic ({alg / 1e6:.2f} MB)", flush=True)
+        ref = outs[variants[0]]
+        for v in variants[1:]:
+            d = (outs[v] - ref).abs().max().item()
+            print(f"    variant {v} vs {variants[0]}: max abs diff {d:.3e}")
+    lib.pivlfn_tune(0, 0)
+
+
+def bench_wc_ablate(args):
+    """Ablation of the shipped warp+correlation kernel (mask bits: 1 no dot products, 2 no gathers, 4 no store, 8 empty)."""
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    B = args.batch
+    for L in [int(x) for x in args.levels.split(",")]:
+        C, n, s = LEVELS[L]
+        f1 = torch.randn(B, n, n, C, device=dev)
+        f2 = torch.randn(B, n, n, C, device=dev)
+        fl = torch.zeros(B, n, n, 4, device=dev)
+        fl[..., :2] = torch.randn(B, n, n, 2, device=dev) * 0.8
+        no = -(-n // s)
+        out = torch.empty(B, no, no, 56, device=dev)
+        for mask in (0, 8, 1, 2, 4, 3, 7):
+            def fn():
+                _lib.check(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), fl.data_ptr() if L < 6 else None, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
+            lib.pivlfn_tune(2, mask)
+            tmin, tmed = time_it(fn)
+            print(f"L{L} B={B} ablation mask {mask}: min {tmin:8.2f} us  med {tmed:8.2f} us", flush=True)
+        lib.pivlfn_tune(2, 0)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["warp_corr", "wc_ablate"])
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--variants", default="1,2,0")
+    ap.add_argument("--levels", default="3,1,2,4,5,6")
+    a = ap.parse_args()
+    {"warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate}[a.what](a)
