@@ -94,6 +94,9 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);
+// 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device
+int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
+                     int k, hipStream_t st);
 
 // ---- warp + correlation (warp_corr.hip) ------------------------------------------------------------
 int launch_warp_corr(const float *f1, const float *f2, const float *flow, float flow_scale, float *out,

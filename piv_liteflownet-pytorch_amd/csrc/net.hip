@@ -23,6 +23,8 @@ struct ConvW {
 struct LevelW {
     float *upconv = nullptr, *upcorr = nullptr;    // depthwise k4 weights [C4][16]
     ConvW M[4], S[4], R[6], feat, dist0, dist1;
+    float *headM = nullptr, *headS = nullptr;      // VALU flow-head weights [k*k][8][2][4]
+    float hbM[2] = {0.f, 0.f}, hbS[2] = {0.f, 0.f};
     float *wx = nullptr, *wy = nullptr;
     float bx = 0.f, by = 0.f;
 };
@@ -122,6 +124,23 @@ static int pack_dw(pivlfn_net *net, const TMap &m, const std::string &name, int 
     return upload(net, h, dev);
 }
 
+// Flow-head weights for conv_head.hip: OIHW [2,32,k,k] -> [tap][channel quad][output][4]
+static int pack_head(pivlfn_net *net, const TMap &m, const std::string &name, int k, float **dev, float bias[2])
+{
+    const pivlfn_tensor *w = find(m, name + ".weight", 2, 32, k, k, 4);
+    const pivlfn_tensor *b = find(m, name + ".bias", 2, 0, 0, 0, 1);
+    if (!w || !b) return PIVLFN_ERR_WEIGHTS;
+    std::vector<float> h((size_t)k * k * 64);
+    for (int t = 0; t < k * k; ++t)
+        for (int q = 0; q < 8; ++q)
+            for (int o = 0; o < 2; ++o)
+                for (int j = 0; j < 4; ++j)
+                    h[(((size_t)t * 8 + q) * 2 + o) * 4 + j] = w->data[((size_t)o * 32 + 4 * q + j) * k * k + t];
+    bias[0] = b->data[0];
+    bias[1] = b->data[1];
+    return upload(net, h, dev);
+}
+
 int net_destroy(pivlfn_net *net)
 {
     if (!net) return PIVLFN_OK;
@@ -200,10 +219,12 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
         TRY(pack_conv(net, m, pm + "conv_M.2", 64, 128, 3, 3, {{128, 128}}, &lw.M[1]));
         TRY(pack_conv(net, m, pm + "conv_M.4", 32, 64, 3, 3, {{64, 64}}, &lw.M[2]));
         TRY(pack_conv(net, m, pm + "conv_M.6", 2, 32, k, k, {{32, 32}}, &lw.M[3]));
+        TRY(pack_head(net, m, pm + "conv_M.6", k, &lw.headM, lw.hbM));
         TRY(pack_conv(net, m, ps + "conv_S.0", 128, 2 * cm + 2, 3, 3, {{cm, cm}, {cm, cm}, {2, 4}}, &lw.S[0]));
         TRY(pack_conv(net, m, ps + "conv_S.2", 64, 128, 3, 3, {{128, 128}}, &lw.S[1]));
         TRY(pack_conv(net, m, ps + "conv_S.4", 32, 64, 3, 3, {{64, 64}}, &lw.S[2]));
         TRY(pack_conv(net, m, ps + "conv_S.6", 2, 32, k, k, {{32, 32}}, &lw.S[3]));
+        TRY(pack_head(net, m, ps + "conv_S.6", k, &lw.headS, lw.hbS));
         const int cfr = L < 5 ? 128 : C_FEAT[L];
         if (L < 5) TRY(pack_conv(net, m, pr + "moduleFeat.0", 128, C_FEAT[L], 1, 1, {{C_FEAT[L], C_FEAT[L]}}, &lw.feat));
         TRY(pack_conv(net, m, pr + "conv_R.0", 128, 3 + cfr, 3, 3, {{3, 4}, {cfr, cfr}}, &lw.R[0]));
@@ -377,13 +398,19 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         RUN(conv(lw.M[0], {{cin, 56, 56}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.M[1], {{bf.t128a, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.M[2], {{bf.t64a, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.M[3], {{bf.t32a, 32, 32}}, bf.flowM, 4, 4, fup, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+        if (g_knob[1] & 1)    // A/B: heads on the matrix cores (30 of 32 output columns wasted)
+            RUN(conv(lw.M[3], {{bf.t32a, 32, 32}}, bf.flowM, 4, 4, fup, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+        else
+            RUN(launch_conv_head(bf.t32a, lw.headM, lw.hbM[0], lw.hbM[1], fup, bf.flowM, B, hh, ww, k, st));
         // ---- Subpixel (:209-217)
         RUN(launch_backwarp_nhwc(f2m, bf.flowM, sc, bf.f2w, B, hh, ww, cm, st));
         RUN(conv(lw.S[0], {{f1m, cm, cm}, {bf.f2w, cm, cm}, {bf.flowM, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.S[1], {{bf.t128a, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.S[2], {{bf.t64a, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.S[3], {{bf.t32a, 32, 32}}, bf.flowS, 4, 4, bf.flowM, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+        if (g_knob[1] & 1)
+            RUN(conv(lw.S[3], {{bf.t32a, 32, 32}}, bf.flowS, 4, 4, bf.flowM, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+        else
+            RUN(launch_conv_head(bf.t32a, lw.headS, lw.hbS[0], lw.hbS[1], bf.flowM, bf.flowS, B, hh, ww, k, st));
         // ---- Regularization (:274-303); note it takes the RAW NetC feature (:361)
         RUN(launch_flow_mean(bf.flowS, bf.partial, bf.mean, B, hh * ww, st));
         RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, sc, bf.misc4, B, hh, ww, st));
