@@ -90,6 +90,22 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
 /* Number of floats `levels` must hold for pivlfn_forward. */
 size_t pivlfn_levels_floats(const pivlfn_net *net, int B, int H, int W);
 
+/* ---- one convolution layer on the network's channels-last layout (what pivlfn_forward launches for every
+ * torch.nn.Conv2d of src/models.py:70-106, 124, 154-163, 197-207, 229-272); exported so the kernel can be checked and
+ * timed on its own.  weight: host, OIHW [cout,cin,kh,kw]; bias: host [cout].
+ * x: [B,H,W,x_stride] (first cin lanes used, x_stride % 4 == 0, lanes cin..roundup(cin,4) must be finite);
+ * y: [B,Ho,Wo,y_stride], lanes cout..min(roundup(cout,4), y_stride) are written as exact zeros;
+ * res (optional): same grid as y, added before the activation; leaky: LeakyReLU(0.1) on the result. */
+typedef struct pivlfn_conv pivlfn_conv;
+int pivlfn_conv_create(const float *weight, const float *bias, int cout, int cin, int kh, int kw, pivlfn_conv **out);
+int pivlfn_conv_destroy(pivlfn_conv *conv);
+int pivlfn_conv2d_nhwc(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                       const float *res, int res_stride, int B, int H, int W, int stride, int pad_y, int pad_x,
+                       int leaky, void *stream);
+/* The 32 -> 2 channel k x k flow head (conv_M.6 / conv_S.6) on its dedicated kernel: x [B,H,W,32], res4/out4 [B,H,W,4]. */
+int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W,
+                          void *stream);
+
 /* ---- measurement hooks.  With profiling on, pivlfn_forward brackets the level-`level` warp+correlation
  * launch with hipEvents on `stream`; pivlfn_profile_read() synchronises those events and returns the
  * accumulated milliseconds and launch count since the last reset. */

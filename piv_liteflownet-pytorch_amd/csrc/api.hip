@@ -3,6 +3,7 @@
 #include "common.h"
 
 struct pivlfn_net;
+struct pivlfn_conv;
 
 namespace pivlfn {
 
@@ -25,6 +26,11 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
 int net_destroy(pivlfn_net *net);
 int net_profile_enable(pivlfn_net *net, int level);
 int net_profile_read(pivlfn_net *net, double *ms, long *launches, int reset);
+int conv_create(const float *weight, const float *bias, int cout, int cin, int kh, int kw, pivlfn_conv **out);
+int conv_destroy(pivlfn_conv *c);
+int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, const float *res, int res_stride,
+                 int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, hipStream_t st);
+int conv_head_forward(const pivlfn_conv *c, const float *x, const float *res4, float *out4, int B, int H, int W, hipStream_t st);
 
 }  // namespace pivlfn
 
@@ -95,6 +101,24 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
                    void *workspace, size_t workspace_bytes, void *stream)
 {
     return net_forward(net, img1, img2, flow, levels, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pivlfn_conv_create(const float *weight, const float *bias, int cout, int cin, int kh, int kw, pivlfn_conv **out)
+{
+    return conv_create(weight, bias, cout, cin, kh, kw, out);
+}
+
+int pivlfn_conv_destroy(pivlfn_conv *conv) { return conv_destroy(conv); }
+
+int pivlfn_conv2d_nhwc(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride, const float *res,
+                       int res_stride, int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, void *stream)
+{
+    return conv_forward(conv, x, x_stride, y, y_stride, res, res_stride, B, H, W, stride, pad_y, pad_x, leaky, (hipStream_t)stream);
+}
+
+int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W, void *stream)
+{
+    return conv_head_forward(conv, x, res4, out4, B, H, W, (hipStream_t)stream);
 }
 
 int pivlfn_profile_enable(pivlfn_net *net, int level) { return net_profile_enable(net, level); }

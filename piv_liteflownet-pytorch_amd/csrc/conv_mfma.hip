@@ -137,6 +137,224 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     }
 }
 
+
+// ---- v2: same tiling, plus register prefetch ------------------------------------------------------------------------
+// The next K-chunk's input patch and weight slab are loaded global -> registers BEFORE the current chunk's MFMAs and
+// written to LDS after them, so the global/L2 latency hides behind the matrix work even with one workgroup per CU
+// (the small pyramid levels, where v1 spent >90% of its time waiting on exposed staging).
+// PMAX / WMAX = compile-time bounds on the 16-byte loads per thread for the patch / the weight slab.
+template <int MT, int NT, int PMAX, int WMAX>
+__global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = NT * 32;
+    constexpr int TH = 4 * MT;
+    const int taps = p.KH * p.KW;
+    const int PH = (TH - 1) * p.S + p.KH;
+    const int PW = 31 * p.S + p.KW;
+    float *patch = smem;
+    float *wts = smem + PH * PW * PIXP;
+
+    const int tiles_x = (p.Wo + 31) >> 5;
+    const int tiles_y = (p.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int n0 = blockIdx.y * BN;
+    const int x0 = tx * 32, y0 = ty * TH;
+    const int ix0 = x0 * p.S - p.padX, iy0 = y0 * p.S - p.padY;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, hh = lane >> 5;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = ((wave * MT + m) * p.S * PW + row * p.S) * PIXP + hh * 4;
+    const int bbase = (hh * BN + row) * 4;
+
+    // this thread's staging slots: patch slot i covers (pixel, quad) = (idx>>1, idx&1), idx = tid + 256*i
+    const int npix2 = PH * PW * 2;
+    const int nw4 = taps * 2 * BN;
+    int poff[PMAX];            // element offset of the pixel inside one image of a source with pixel stride 1 (x stride later), -1 = zero
+    int plds[PMAX];            // LDS float offset
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const int idx = tid + 256 * i;
+        const int pix = idx >> 1, q = idx & 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool ok = idx < npix2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        poff[i] = ok ? (b * p.H + iy) * p.W + ix : -1;
+        plds[i] = idx < npix2 ? pix * PIXP + q * 4 : -1;
+    }
+    const int q4 = (tid & 1) * 4;
+    int woff[WMAX];            // float4 index inside the chunk's slab (relative to n0), -1 = none
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) {
+        const int idx = tid + 256 * i;
+        const int th = idx / BN, n = idx - th * BN;
+        woff[i] = idx < nw4 ? th * p.cout_pad + n : -1;
+    }
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + n0;
+    const size_t wchunk = (size_t)taps * 2 * p.cout_pad;
+
+    f32x4 pr[PMAX], wr[WMAX];
+    int seg = 0, c0 = 0;
+    const float *sp = p.seg[0].ptr;
+    int scl = p.seg[0].cload, sst = p.seg[0].stride;
+
+#define CONV2_LOAD(CH)                                                                            \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < PMAX; ++i) {                                        \
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                       \
+            if (poff[i] >= 0 && c0 + q4 < scl) v = *reinterpret_cast<const f32x4 *>(sp + (size_t)poff[i] * sst + c0 + q4); \
+            pr[i] = v;                                                                            \
+        }                                                                                         \
+        const f32x4 *wc_ = wsrc + (size_t)(CH)*wchunk;                                            \
+        _Pragma("unroll") for (int i = 0; i < WMAX; ++i)                                          \
+            if (woff[i] >= 0) wr[i] = wc_[woff[i]];                                               \
+    } while (0)
+
+    CONV2_LOAD(0);
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        // registers -> LDS (waits for the loads of this chunk)
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i)
+            if (plds[i] >= 0) *reinterpret_cast<f32x4 *>(patch + plds[i]) = pr[i];
+#pragma unroll
+        for (int i = 0; i < WMAX; ++i)
+            if (woff[i] >= 0) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+        __syncthreads();
+        // advance to the next chunk's source and put its loads in flight
+        if (chunk + 1 < p.nchunk) {
+            c0 += 8;
+            if (c0 >= scl) {
+                ++seg;
+                c0 = 0;
+                sp = p.seg[seg].ptr; scl = p.seg[seg].cload; sst = p.seg[seg].stride;
+            }
+            CONV2_LOAD(chunk + 1);
+        }
+        int tap = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            for (int kx = 0; kx < p.KW; ++kx, ++tap) {
+                const int toff = (ky * PW + kx) * PIXP;
+                f32x4 a[MT], bq[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4 *>(patch + abase[m] + toff);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    bq[n] = *reinterpret_cast<const f32x4 *>(wts + tap * 2 * BN * 4 + bbase + n * 128);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bq[n][j], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();       // all waves done with this chunk's LDS image before it is overwritten
+    }
+#undef CONV2_LOAD
+
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ch = n0 + n * 32 + row;
+        if (ch >= p.cout_store) continue;
+        const float bias = p.bias[ch];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + wave * MT + m;
+            if (oy >= p.Ho) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ox >= p.Wo) continue;
+                const size_t pix = (size_t)(b * p.Ho + oy) * p.Wo + ox;
+                float v = acc[m][n][r] + bias;
+                if (p.res) v += p.res[pix * p.res_stride + ch];
+                if (p.lrelu) v = lrelu01(v);
+                p.out[pix * p.out_stride + ch] = v;
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int PMAX, int WMAX>
+static int launch_t2(const ConvParams &p, hipStream_t st)
+{
+    constexpr int TH = 4 * MT, BN = NT * 32;
+    const int PH = (TH - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
+    const size_t lds = ((size_t)PH * PW * PIXP + (size_t)p.KH * p.KW * 2 * BN * 4) * sizeof(float);
+    PIV_REQUIRE(lds <= 160 * 1024, "conv: LDS tile of %zu bytes exceeds 160 KiB (k=%dx%d s=%d)", lds, p.KH, p.KW, p.S);
+    PIV_REQUIRE(PH * PW * 2 <= 256 * PMAX && p.KH * p.KW * 2 * BN <= 256 * WMAX, "conv: internal staging bound exceeded");
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma2_kernel<MT, NT, PMAX, WMAX>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        attr_set = true;
+    }
+    const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
+    dim3 grid(tiles, p.cout_pad / BN);
+    hipLaunchKernelGGL((conv_mfma2_kernel<MT, NT, PMAX, WMAX>), grid, dim3(256), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+// Tile choice for v2.  Staging loads per thread: patch = PH*PW*2/256, slab = taps*2*BN/256 (16-byte each).
+static int launch_conv2(const ConvParams &p, hipStream_t st)
+{
+    const int taps = p.KH * p.KW;
+    const long px_blocks1 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 4) * p.B;     // workgroups with MT = 1 per N block
+    // widest N tile (32*nt channels) that still leaves >= 256 workgroups; with fewer the tile is narrowed so more CUs get
+    // work (the input patch is then re-staged once per N block, which is cheap at the small levels where this happens)
+    int nt = 1;
+    for (int cand = 4; cand >= 1; --cand) {
+        if (p.cout_pad % (cand * 32)) continue;
+        if (px_blocks1 * (p.cout_pad / (cand * 32)) >= 256 || cand == 1) { nt = cand; break; }
+    }
+    int mt = (px_blocks1 / 2) * (p.cout_pad / (nt * 32)) >= 512 ? 2 : 1;
+    auto need = [&](int mt_, int nt_, int &pm, int &wm) {
+        const int PH = (4 * mt_ - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
+        pm = cdiv(PH * PW * 2, 256);
+        wm = cdiv(taps * 2 * nt_ * 32, 256);
+    };
+    int pm, wm;
+    need(mt, nt, pm, wm);
+    if ((pm > 3 || wm > 9) && mt == 2 && nt >= 3) { mt = 1; need(mt, nt, pm, wm); }   // keep the big-staging class under 256 VGPRs
+    if (pm > 9 || wm > 13) return -1;      // not covered: caller falls back to v1
+    const bool small = pm <= 3 && wm <= 9;
+#define PICK(MT_, NT_)                                                                     \
+    (small ? launch_t2<MT_, NT_, 3, 9>(p, st) : launch_t2<MT_, NT_, 9, 13>(p, st))
+    if (mt == 2) {
+        switch (nt) {
+            case 4: return small ? launch_t2<2, 4, 3, 9>(p, st) : -1;
+            case 3: return small ? launch_t2<2, 3, 3, 9>(p, st) : -1;
+            case 2: return PICK(2, 2);
+            default: return PICK(2, 1);
+        }
+    }
+    switch (nt) {
+        case 4: return PICK(1, 4);
+        case 3: return PICK(1, 3);
+        case 2: return PICK(1, 2);
+        default: return PICK(1, 1);
+    }
+#undef PICK
+}
+
 template <int MT, int NT>
 static int launch_t(const ConvParams &p, hipStream_t st)
 {
@@ -164,6 +382,10 @@ int launch_conv(const ConvParams &p, hipStream_t st)
     PIV_REQUIRE(p.B > 0 && p.H > 0 && p.W > 0 && p.Ho > 0 && p.Wo > 0, "conv: empty shape");
     for (int s = 0; s < p.nseg; ++s)
         PIV_REQUIRE(p.seg[s].cload % 4 == 0 && p.seg[s].stride % 4 == 0 && p.seg[s].ptr, "conv: segment %d misaligned", s);
+    if (!(g_knob[1] & 2)) {               // shipped path: v2 (register prefetch); knob bit 1 forces v1 for A/B
+        const int rc = launch_conv2(p, st);
+        if (rc >= 0) return rc;
+    }
     int nt;
     if (p.cout_pad % 128 == 0) nt = 4;
     else if (p.cout_pad % 96 == 0) nt = 3;

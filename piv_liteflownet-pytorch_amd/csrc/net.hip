@@ -31,6 +31,15 @@ struct LevelW {
 
 }  // namespace pivlfn
 
+struct pivlfn_net;
+struct pivlfn_conv {
+    pivlfn::ConvW cw;
+    int cin = 0;
+    float *head = nullptr;     // set when the layer is a 32->2 kxk flow head
+    float hb[2] = {0.f, 0.f};
+    pivlfn_net *owner = nullptr;   // holds the device allocations
+};
+
 struct pivlfn_net {
     float scale[7];
     int lowest;
@@ -251,6 +260,63 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
 #undef TRY
     *out = net;
     return PIVLFN_OK;
+}
+
+// ---- stand-alone convolution layer (tests, micro-benchmarks) ---------------------------------------------------------
+int conv_create(const float *weight, const float *bias, int cout, int cin, int kh, int kw, pivlfn_conv **out)
+{
+    PIV_REQUIRE(weight && bias && out && cout > 0 && cin > 0 && kh > 0 && kw > 0, "conv_create: bad arguments");
+    pivlfn_tensor t[2];
+    t[0].name = "c.weight"; t[0].data = weight; t[0].ndim = 4;
+    t[0].shape[0] = cout; t[0].shape[1] = cin; t[0].shape[2] = kh; t[0].shape[3] = kw;
+    t[1].name = "c.bias"; t[1].data = bias; t[1].ndim = 1;
+    t[1].shape[0] = cout; t[1].shape[1] = t[1].shape[2] = t[1].shape[3] = 0;
+    TMap m;
+    m["c.weight"] = &t[0];
+    m["c.bias"] = &t[1];
+    pivlfn_conv *c = new pivlfn_conv();
+    c->owner = new pivlfn_net();
+    c->cin = cin;
+    int rc = pack_conv(c->owner, m, "c", cout, cin, kh, kw, {{cin, rup(cin, 4)}}, &c->cw);
+    if (!rc && cout == 2 && cin == 32 && kh == kw && (kh == 3 || kh == 5 || kh == 7)) rc = pack_head(c->owner, m, "c", kh, &c->head, c->hb);
+    if (rc) { net_destroy(c->owner); delete c; return rc; }
+    *out = c;
+    return PIVLFN_OK;
+}
+
+int conv_destroy(pivlfn_conv *c)
+{
+    if (!c) return PIVLFN_OK;
+    net_destroy(c->owner);
+    delete c;
+    return PIVLFN_OK;
+}
+
+int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, const float *res, int res_stride,
+                 int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, hipStream_t st)
+{
+    PIV_REQUIRE(c && x && y, "conv2d: null argument");
+    PIV_REQUIRE(x_stride % 4 == 0 && x_stride >= rup(c->cin, 4), "conv2d: x_stride=%d must be a multiple of 4 and >= %d", x_stride, rup(c->cin, 4));
+    PIV_REQUIRE(y_stride >= c->cw.cout, "conv2d: y_stride=%d < cout=%d", y_stride, c->cw.cout);
+    PIV_REQUIRE(stride >= 1 && pad_y >= 0 && pad_x >= 0 && H + 2 * pad_y >= c->cw.KH && W + 2 * pad_x >= c->cw.KW, "conv2d: bad geometry");
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.seg[0] = ConvSeg{x, rup(c->cin, 4), x_stride};
+    p.nseg = 1;
+    p.wpk = c->cw.wpk; p.bias = c->cw.bias; p.out = y; p.out_stride = y_stride;
+    p.cout_store = std::min(rup(c->cw.cout, 4), y_stride);
+    p.cout_pad = c->cw.cout_pad; p.res = res; p.res_stride = res_stride;
+    p.B = B; p.H = H; p.W = W; p.KH = c->cw.KH; p.KW = c->cw.KW; p.S = stride; p.padY = pad_y; p.padX = pad_x;
+    p.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
+    p.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
+    p.nchunk = c->cw.nchunk; p.lrelu = leaky;
+    return launch_conv(p, st);
+}
+
+int conv_head_forward(const pivlfn_conv *c, const float *x, const float *res4, float *out4, int B, int H, int W, hipStream_t st)
+{
+    PIV_REQUIRE(c && c->head, "conv_head: the layer is not a 32->2 kxk flow head");
+    return launch_conv_head(x, c->head, c->hb[0], c->hb[1], res4, out4, B, H, W, c->cw.KH, st);
 }
 
 // ---- workspace plan -------------------------------------------------------------------------------------------

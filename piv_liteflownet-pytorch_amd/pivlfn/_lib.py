@@ -30,6 +30,10 @@ SIGNATURES = {
     "pivlfn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_void_p] + [ctypes.c_int] * 3),
     "pivlfn_levels_floats": (ctypes.c_size_t, [ctypes.c_void_p] + [ctypes.c_int] * 3),
     "pivlfn_forward": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "pivlfn_conv_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_void_p)]),
+    "pivlfn_conv_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pivlfn_conv2d_nhwc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
+    "pivlfn_conv_head_nhwc": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "pivlfn_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pivlfn_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
 }

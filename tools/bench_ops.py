@@ -89,11 +89,64 @@ def bench_wc_ablate(args):
         lib.pivlfn_tune(2, 0)
 
 
+CONV_SHAPES = [
+    # name, cout, cin, k, stride, H(=W) at the 1024x1024 PIV forward, batch multiplier
+    ("L1 R.conv_R.2 128->128", 128, 128, 3, 1, 1024, 1), ("L1 S.conv_S.0 130->128", 128, 136, 3, 1, 1024, 1),
+    ("L1 M.conv_M.0 49->128", 128, 56, 3, 1, 1024, 1), ("L1 conv 128->64", 64, 128, 3, 1, 1024, 1),
+    ("L1 conv 64->64", 64, 64, 3, 1, 1024, 1), ("L1 conv 64->32", 32, 64, 3, 1, 1024, 1), ("L1 conv 32->32", 32, 32, 3, 1, 1024, 1),
+    ("L2 conv 128->128", 128, 128, 3, 1, 512, 1), ("L3 conv 128->128", 128, 128, 3, 1, 256, 1),
+    ("L4 conv 128->128", 128, 128, 3, 1, 128, 1), ("L5 conv 128->128", 128, 128, 3, 1, 64, 1), ("L6 conv 128->128", 128, 128, 3, 1, 32, 1),
+    ("L6 S.conv_S.0 386->128", 128, 392, 3, 1, 32, 1), ("L5 S.conv_S.0 258->128", 128, 264, 3, 1, 64, 1),
+    ("NetC.conv1 7x7 3->32", 32, 4, 7, 1, 1024, 2), ("NetC.conv2.0 s2 32->32", 32, 32, 3, 2, 1024, 2),
+    ("NetC.conv3.0 s2 32->64", 64, 32, 3, 2, 512, 2), ("NetC.conv5.0 s2 96->128", 128, 96, 3, 2, 128, 2),
+    ("L1 moduleFeat 1x1 32->128", 128, 32, 1, 1, 1024, 1), ("L1 dist 7x1 32->49", 49, 32, (7, 1), 1, 1024, 1),
+    ("L1 dist 1x7 49->49", 49, 52, (1, 7), 1, 1024, 1),
+]
+
+
+def bench_conv(args):
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    variants = [int(v) for v in args.variants.split(",")]
+    for name, co, ci, k, s, n, bm in CONV_SHAPES:
+        if args.filter and args.filter not in name:
+            continue
+        kh, kw = (k, k) if isinstance(k, int) else k
+        B = args.batch * bm
+        w = (torch.randn(co, ci, kh, kw) / (ci * kh * kw) ** 0.5).contiguous()
+        b = torch.randn(co).contiguous()
+        h = ctypes.c_void_p()
+        _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
+        x = torch.randn(B, n, n, ci, device=dev)
+        no = (n + 2 * (kh // 2) - kh) // s + 1
+        mo = (n + 2 * (kw // 2) - kw) // s + 1
+        ys = -(-co // 4) * 4
+        flop = 2.0 * B * no * mo * co * ci * kh * kw
+        outs = {}
+        for v in variants:
+            y = torch.empty(B, no, mo, ys, device=dev)
+            outs[v] = y
+
+            def fn(v=v, y=y):
+                lib.pivlfn_tune(1, v)
+                _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+            tmin, tmed = time_it(fn, n=10 if flop > 2e10 else 30, rounds=4)
+            print(f"{name:28s} B={B} variant {v}: min {tmin:9.1f} us  med {tmed:9.1f} us  {flop / tmin / 1e6:7.1f} TFLOP/s (staged K)", flush=True)
+        for v in variants[1:]:
+            d = (outs[v] - outs[variants[0]]).abs().max().item()
+            print(f"    variant {v} vs {variants[0]}: max abs diff {d:.3e}")
+        lib.pivlfn_conv_destroy(h)
+    lib.pivlfn_tune(1, 0)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["warp_corr", "wc_ablate"])
+    ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv"])
+    ap.add_argument("--filter", default="")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--variants", default="1,2,0")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
     a = ap.parse_args()
-    {"warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate}[a.what](a)
+    {"warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv}[a.what](a)
