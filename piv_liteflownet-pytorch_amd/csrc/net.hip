@@ -21,7 +21,7 @@ struct ConvW {
 };
 
 struct LevelW {
-    float *upconv = nullptr, *upcorr = nullptr;    // depthwise k4 weights [C4][16]
+    float *upconv = nullptr, *upcorr = nullptr;    // depthwise k4 weights [16 taps][C4]
     ConvW M[4], S[4], R[6], feat, dist0, dist1;
     float *headM = nullptr, *headS = nullptr;      // VALU flow-head weights [k*k][8][2][4]
     float hbM[2] = {0.f, 0.f}, hbS[2] = {0.f, 0.f};
@@ -127,9 +127,9 @@ static int pack_dw(pivlfn_net *net, const TMap &m, const std::string &name, int 
 {
     const pivlfn_tensor *w = find(m, name, C, 1, 4, 4, 4);
     if (!w) return PIVLFN_ERR_WEIGHTS;
-    std::vector<float> h((size_t)cpad * 16, 0.f);
+    std::vector<float> h((size_t)cpad * 16, 0.f);      // [16 taps][cpad channels]
     for (int c = 0; c < C; ++c)
-        for (int t = 0; t < 16; ++t) h[(size_t)c * 16 + t] = w->data[(size_t)c * 16 + t];
+        for (int t = 0; t < 16; ++t) h[(size_t)t * cpad + c] = w->data[(size_t)c * 16 + t];
     return upload(net, h, dev);
 }
 

@@ -121,37 +121,37 @@ int launch_resize_nchw(const float *in, float *out, int B, int C, int H, int W, 
 
 // ---- upConv_M / upCorr_M (:144-145, 151-152): depthwise ConvTranspose2d k4 s2 p1, no bias ----------------------
 // out[oy,ox,c] = sum over the (at most 2x2) input pixels with oy = 2*iy - 1 + ky, ox = 2*ix - 1 + kx.
-// w: [C4*4][16] (zero rows for padding channels, so padding lanes stay exact zeros).
+// w: [16 taps][C4] (zero lanes for padding channels, so padding lanes stay exact zeros); 32-bit index math.
 __global__ __launch_bounds__(256) void dwconvT_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                       float *__restrict__ out, int B, int H, int W, int Q, int sin, int sout)
 {
-    const int Ho = 2 * H, Wo = 2 * W;
-    const size_t total = (size_t)B * Ho * Wo * Q;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % Q);
-        size_t r = i / Q;
-        const int ox = (int)(r % Wo);
+    const unsigned Ho = 2 * H, Wo = 2 * W;
+    const unsigned total = (unsigned)B * Ho * Wo * Q;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned q = i % Q;
+        unsigned r = i / Q;
+        const unsigned ox = r % Wo;
         r /= Wo;
-        const int oy = (int)(r % Ho);
-        const int b = (int)(r / Ho);
+        const unsigned oy = r % Ho;
+        const unsigned b = r / Ho;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int ky = ky0 + 2 * a;
-            const int iy = (oy + 1 - ky) >> 1;
+            const int iy = ((int)oy + 1 - ky) >> 1;
             if (iy < 0 || iy >= H) continue;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int kx = kx0 + 2 * c;
-                const int ix = (ox + 1 - kx) >> 1;
+                const int ix = ((int)ox + 1 - kx) >> 1;
                 if (ix < 0 || ix >= W) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + iy) * W + ix) * sin + 4 * q);
-                const int t = ky * 4 + kx;
-                acc[0] = fmaf(v[0], w[(4 * q + 0) * 16 + t], acc[0]);
-                acc[1] = fmaf(v[1], w[(4 * q + 1) * 16 + t], acc[1]);
-                acc[2] = fmaf(v[2], w[(4 * q + 2) * 16 + t], acc[2]);
-                acc[3] = fmaf(v[3], w[(4 * q + 3) * 16 + t], acc[3]);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + ((ky * 4 + kx) * Q + q) * 4);
+                acc[0] = fmaf(v[0], wv[0], acc[0]);
+                acc[1] = fmaf(v[1], wv[1], acc[1]);
+                acc[2] = fmaf(v[2], wv[2], acc[2]);
+                acc[3] = fmaf(v[3], wv[3], acc[3]);
             }
         }
         *reinterpret_cast<f32x4 *>(out + ((size_t)(b * Ho + oy) * Wo + ox) * sout + 4 * q) = acc;
@@ -164,26 +164,26 @@ int launch_dwconvT(const float *in, const float *w, float *out, int B, int H, in
     (void)C;
     const int Q = cstore / 4;
     const size_t total = (size_t)B * 4 * H * W * Q;
+    PIV_REQUIRE(total < 0x7fffffffull, "dwconvT: %zu work items exceed the 32-bit index range", total);
     hipLaunchKernelGGL(dwconvT_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, w, out, B, H, W, Q, stride_in, stride_out);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
 
-
 // ---- Subpixel's backwarp(feat2, flow*scale) (:214): [B,H,W,C] ----------------------------------------------------
 __global__ __launch_bounds__(256) void backwarp_nhwc_kernel(const float *__restrict__ in, const float *__restrict__ flow4,
                                                             float scale, float *__restrict__ out, int B, int H, int W, int C)
 {
-    const int Q = C / 4;
-    const size_t total = (size_t)B * H * W * Q;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % Q);
-        const size_t pix = i / Q;
-        const int x = (int)(pix % W);
-        const size_t r = pix / W;
-        const int y = (int)(r % H);
-        const int b = (int)(r / H);
-        const float2 uv = *reinterpret_cast<const float2 *>(flow4 + pix * 4);
+    const unsigned Q = C / 4;
+    const unsigned total = (unsigned)B * H * W * Q;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned q = i % Q;
+        const unsigned pix = i / Q;
+        const int x = (int)(pix % (unsigned)W);
+        const unsigned r = pix / (unsigned)W;
+        const int y = (int)(r % (unsigned)H);
+        const int b = (int)(r / (unsigned)H);
+        const float2 uv = *reinterpret_cast<const float2 *>(flow4 + (size_t)pix * 4);
         const Taps t = make_taps((float)x + uv.x * scale, (float)y + uv.y * scale, H, W);
         const float *base = in + (size_t)b * H * W * C + 4 * q;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void backwarp_nhwc_kernel(const float *__restr
         if (t.o01 >= 0) v += t.w01 * *reinterpret_cast<const f32x4 *>(base + (size_t)t.o01 * C);
         if (t.o10 >= 0) v += t.w10 * *reinterpret_cast<const f32x4 *>(base + (size_t)t.o10 * C);
         if (t.o11 >= 0) v += t.w11 * *reinterpret_cast<const f32x4 *>(base + (size_t)t.o11 * C);
-        *reinterpret_cast<f32x4 *>(out + pix * C + 4 * q) = v;
+        *reinterpret_cast<f32x4 *>(out + (size_t)pix * C + 4 * q) = v;
     }
 }
 
@@ -200,6 +200,7 @@ int launch_backwarp_nhwc(const float *in, const float *flow4, float scale, float
 {
     PIV_REQUIRE(C % 4 == 0, "backwarp (channels-last): C=%d must be a multiple of 4", C);
     const size_t total = (size_t)B * H * W * (C / 4);
+    PIV_REQUIRE(total < 0x7fffffffull, "backwarp: %zu work items exceed the 32-bit index range", total);
     hipLaunchKernelGGL(backwarp_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, flow4, scale, out, B, H, W, C);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
@@ -267,12 +268,12 @@ __global__ __launch_bounds__(256) void reg_prep_kernel(const f32x4 *__restrict__
                                                        const f32x4 *__restrict__ flow4, const float *__restrict__ mean,
                                                        float scale, f32x4 *__restrict__ misc4, int B, int H, int W)
 {
-    const size_t total = (size_t)B * H * W;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = (int)(i % W);
-        const size_t r = i / W;
-        const int y = (int)(r % H);
-        const int b = (int)(r / H);
+    const unsigned total = (unsigned)B * H * W;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int x = (int)(i % (unsigned)W);
+        const unsigned r = i / (unsigned)W;
+        const int y = (int)(r % (unsigned)H);
+        const int b = (int)(r / (unsigned)H);
         const f32x4 fl = flow4[i];
         const Taps t = make_taps((float)x + fl[0] * scale, (float)y + fl[1] * scale, H, W);
         const f32x4 *base = img2 + (size_t)b * H * W;
@@ -313,14 +314,14 @@ __global__ __launch_bounds__(256) void reg_tail_kernel(const float *__restrict__
 {
     constexpr int KK = K * K, P = K / 2;
     const size_t img = (size_t)H * W;
-    const size_t total = (size_t)B * img;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = (int)(i % W);
-        const size_t r = i / W;
-        const int y = (int)(r % H);
-        const int b = (int)(r / H);
+    const unsigned total = (unsigned)B * H * W;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int x = (int)(i % (unsigned)W);
+        const unsigned r = i / (unsigned)W;
+        const int y = (int)(r % (unsigned)H);
+        const int b = (int)(r / (unsigned)H);
         float e[KK];
-        const float *dp = dist + i * dstride;
+        const float *dp = dist + (size_t)i * dstride;
         float m = -INFINITY;
 #pragma unroll
         for (int c = 0; c < KK; ++c) {
