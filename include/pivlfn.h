@@ -106,11 +106,13 @@ int pivlfn_conv2d_nhwc(const pivlfn_conv *conv, const float *x, int x_stride, fl
 int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W,
                           void *stream);
 
-/* ---- measurement hooks.  With profiling on, pivlfn_forward brackets the level-`level` warp+correlation
- * launch with hipEvents on `stream`; pivlfn_profile_read() synchronises those events and returns the
- * accumulated milliseconds and launch count since the last reset. */
+/* ---- measurement hooks.  With profiling on, pivlfn_forward times the level-`level` warp+correlation launch
+ * with HIP events on `stream` in two ways: start/stop events attached to the dispatch itself
+ * (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps) and a plain hipEventRecord pair around it
+ * (which also contains the marker packets' own cost).  pivlfn_profile_read() synchronises those events and
+ * returns both accumulated times in milliseconds and the launch count since the last reset. */
 int pivlfn_profile_enable(pivlfn_net *net, int level);   /* level 1..6, 0 = off */
-int pivlfn_profile_read(pivlfn_net *net, double *ms_total, long *launches, int reset);
+int pivlfn_profile_read(pivlfn_net *net, double *ms_dispatch, double *ms_event_pair, long *launches, int reset);
 
 #ifdef __cplusplus
 }

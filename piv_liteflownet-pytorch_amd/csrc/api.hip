@@ -25,7 +25,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
                 void *ws, size_t ws_bytes, hipStream_t st);
 int net_destroy(pivlfn_net *net);
 int net_profile_enable(pivlfn_net *net, int level);
-int net_profile_read(pivlfn_net *net, double *ms, long *launches, int reset);
+int net_profile_read(pivlfn_net *net, double *ms, double *ms_empty, long *launches, int reset);
 int conv_create(const float *weight, const float *bias, int cout, int cin, int kh, int kw, pivlfn_conv **out);
 int conv_destroy(pivlfn_conv *c);
 int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, const float *res, int res_stride,
@@ -123,9 +123,9 @@ int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *
 
 int pivlfn_profile_enable(pivlfn_net *net, int level) { return net_profile_enable(net, level); }
 
-int pivlfn_profile_read(pivlfn_net *net, double *ms_total, long *launches, int reset)
+int pivlfn_profile_read(pivlfn_net *net, double *ms_total, double *ms_empty_pairs, long *launches, int reset)
 {
-    return net_profile_read(net, ms_total, launches, reset);
+    return net_profile_read(net, ms_total, ms_empty_pairs, launches, reset);
 }
 
 }  // extern "C"

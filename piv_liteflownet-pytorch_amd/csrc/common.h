@@ -101,6 +101,7 @@ int launch_conv_head(const float *x, const float *w, float b0, float b1, const f
 // ---- warp + correlation (warp_corr.hip) ------------------------------------------------------------
 int launch_warp_corr(const float *f1, const float *f2, const float *flow, float flow_scale, float *out,
                      int B, int C, int H, int W, int stride, int leaky, bool nhwc, hipStream_t st);
+void warp_corr_time_next(hipEvent_t start, hipEvent_t stop);   // attach start/stop events to the next channels-last launch
 int launch_backwarp_nchw(const float *in, const float *flow, float *out, int B, int C, int H, int W, hipStream_t st);
 
 // ---- small ops (ops.hip); NHWC unless noted ----------------------------------------------------------

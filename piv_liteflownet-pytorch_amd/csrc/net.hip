@@ -159,13 +159,14 @@ int net_destroy(pivlfn_net *net)
     return PIVLFN_OK;
 }
 
-// hipEvent pairs around the chosen level's warp+correlation launch; read back after the timed region.
+// Per timed launch of the chosen level's warp+correlation: events [0,1] = start/stop of the dispatch itself
+// (hipExtLaunchKernelGGL), events [2,3] = a plain hipEventRecord pair around it.  Read back after the timed region.
 int net_profile_enable(pivlfn_net *net, int level)
 {
     PIV_REQUIRE(net && level >= 0 && level <= 6, "profile_enable: bad arguments");
     net->prof_level = level;
     if (level && net->ev.empty()) {
-        net->ev.resize(2 * 4096);
+        net->ev.resize(4 * 4096);
         for (auto &e : net->ev) PIV_CHECK_HIP(hipEventCreate(&e));
     }
     net->ev_used = 0;
@@ -173,18 +174,21 @@ int net_profile_enable(pivlfn_net *net, int level)
     return PIVLFN_OK;
 }
 
-int net_profile_read(pivlfn_net *net, double *ms, long *launches, int reset)
+int net_profile_read(pivlfn_net *net, double *ms, double *ms_empty, long *launches, int reset)
 {
-    PIV_REQUIRE(net && ms && launches, "profile_read: null argument");
-    double tot = 0.0;
-    for (size_t i = 0; i + 1 < net->ev_used; i += 2) {
-        PIV_CHECK_HIP(hipEventSynchronize(net->ev[i + 1]));
-        float t = 0.f;
+    PIV_REQUIRE(net && ms && ms_empty && launches, "profile_read: null argument");
+    double tot = 0.0, empty = 0.0;
+    for (size_t i = 0; i + 3 < net->ev_used; i += 4) {
+        PIV_CHECK_HIP(hipEventSynchronize(net->ev[i + 3]));
+        float t = 0.f, e = 0.f;
         PIV_CHECK_HIP(hipEventElapsedTime(&t, net->ev[i], net->ev[i + 1]));
+        PIV_CHECK_HIP(hipEventElapsedTime(&e, net->ev[i + 2], net->ev[i + 3]));
         tot += t;
+        empty += e;
     }
     *ms = tot;
-    *launches = (long)(net->ev_used / 2);
+    *ms_empty = empty;
+    *launches = (long)(net->ev_used / 4);
     if (reset) { net->ev_used = 0; net->ev_dropped = 0; }
     return PIVLFN_OK;
 }
@@ -451,11 +455,18 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             RUN(launch_dwconvT(prev, lw.upconv, bf.flow_up, B, h[L + 1], w[L + 1], 2, 4, 4, 4, st));
             fup = bf.flow_up;
         }
-        const bool prof = net->prof_level == L && net->ev_used + 2 <= net->ev.size();
+        const bool prof = net->prof_level == L && net->ev_used + 4 <= net->ev.size();
         if (net->prof_level == L && !prof) net->ev_dropped++;
-        if (prof) PIV_CHECK_HIP(hipEventRecord(net->ev[net->ev_used], st));
+        if (prof) {
+            // (a) start/stop events attached to the dispatch itself; (b) a plain event pair around it (reported for reference)
+            warp_corr_time_next(net->ev[net->ev_used], net->ev[net->ev_used + 1]);
+            PIV_CHECK_HIP(hipEventRecord(net->ev[net->ev_used + 2], st));
+        }
         RUN(launch_warp_corr(f1m, f2m, fup, sc, bf.corr, B, cm, hh, ww, s, 1, true, st));
-        if (prof) { PIV_CHECK_HIP(hipEventRecord(net->ev[net->ev_used + 1], st)); net->ev_used += 2; }
+        if (prof) {
+            PIV_CHECK_HIP(hipEventRecord(net->ev[net->ev_used + 3], st));
+            net->ev_used += 4;
+        }
         const float *cin = bf.corr;
         if (s == 2) {
             RUN(launch_dwconvT(bf.corr, lw.upcorr, bf.corr_up, B, hh / 2, ww / 2, 49, 56, 56, 56, st));

@@ -19,6 +19,7 @@
 //   * results are transposed through LDS so the [B,Ho,Wo,56] store is made of whole 16-byte lanes;
 //   * workgroup ids are remapped so every XCD owns a contiguous band of tiles (halo re-reads hit its L2).
 #include <cstdlib>
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace pivlfn {
@@ -29,6 +30,11 @@ constexpr int TO = 8;
 constexpr int TP = TO + 6;
 constexpr int NPOS = TP * TP;
 constexpr int OUTC = 56;
+
+// Optional start/stop events attached to the next warp+correlation dispatch itself (hipExtLaunchKernelGGL): the
+// same start/end timestamps rocprofv3 reports, with no marker packets in between.  Set by pivlfn_forward's profiling hook.
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void warp_corr_time_next(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 
 struct WcParams {
     const float *f1, *f2, *flow;
@@ -583,7 +589,12 @@ static int launch_wc3(const WcParams &p, hipStream_t st)
         attr = true;
     }
     const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
-    hipLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW>), dim3(nblk), dim3(512), lds, st, p);
+    if (g_ev_start) {
+        hipExtLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW>), dim3(nblk), dim3(512), lds, st, g_ev_start, g_ev_stop, 0, p);
+        g_ev_start = g_ev_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW>), dim3(nblk), dim3(512), lds, st, p);
+    }
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
@@ -776,7 +787,12 @@ static int launch_wc4(const WcParams &p, hipStream_t st)
         attr = true;
     }
     const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
-    hipLaunchKernelGGL((warp_corr_v4_kernel<HASFLOW>), dim3(nblk), dim3(1024), lds, st, p);
+    if (g_ev_start) {
+        hipExtLaunchKernelGGL((warp_corr_v4_kernel<HASFLOW>), dim3(nblk), dim3(1024), lds, st, g_ev_start, g_ev_stop, 0, p);
+        g_ev_start = g_ev_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL((warp_corr_v4_kernel<HASFLOW>), dim3(nblk), dim3(1024), lds, st, p);
+    }
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }

@@ -35,7 +35,7 @@ SIGNATURES = {
     "pivlfn_conv2d_nhwc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "pivlfn_conv_head_nhwc": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "pivlfn_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    "pivlfn_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
+    "pivlfn_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
 }
 
 _lib = None

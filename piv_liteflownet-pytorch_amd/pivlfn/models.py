@@ -195,9 +195,10 @@ class LiteFlowNet(torch.nn.Module):
         _lib.check(_lib.load().pivlfn_profile_enable(self._native(), int(level)), "profile_enable")
 
     def profile_read(self, reset: bool = True):
-        ms, n = ctypes.c_double(), ctypes.c_long()
-        _lib.check(_lib.load().pivlfn_profile_read(self._native(), ctypes.byref(ms), ctypes.byref(n), int(reset)), "profile_read")
-        return ms.value, n.value
+        ms, empty, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        _lib.check(_lib.load().pivlfn_profile_read(self._native(), ctypes.byref(ms), ctypes.byref(empty), ctypes.byref(n), int(reset)),
+                   "profile_read")
+        return ms.value, empty.value, n.value
 
 
 def _build(model: str, params: Optional[OrderedDict], version: int) -> LiteFlowNet:
