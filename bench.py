@@ -91,13 +91,19 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    backend = os.environ.get("PIVLFN_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 control flow on a 1-GPU box
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     import pivlfn
     from pivlfn import synth
@@ -110,7 +116,8 @@ def main():
     net = pivlfn.Network(model=args.model, params=wts).to(dev).eval()
 
     div = 2 ** (net.lowest_level - 1)
-    gathered = [torch.empty(world * B, 2, S // div, S // div, device=dev) for _ in range(2)] if world > 1 else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty(world * B, 2, S // div, S // div, device=gdev) for _ in range(2)] if world > 1 else None
     pending = [None, None]
 
     def step(i):
@@ -119,7 +126,10 @@ def main():
             k = i & 1
             if pending[k] is not None:
                 pending[k].wait()
-            pending[k] = dist.all_gather_into_tensor(gathered[k], flow, async_op=True)
+            if backend == "nccl":
+                pending[k] = dist.all_gather_into_tensor(gathered[k], flow, async_op=True)
+            else:
+                pending[k] = dist.all_gather(list(gathered[k].view(world, B, 2, S // div, S // div).unbind(0)), flow.cpu(), async_op=True)
         return flow
 
     def fence():
@@ -146,7 +156,7 @@ def main():
     if L:
         net.profile_enable(0)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
