@@ -19,6 +19,7 @@
 //     16-byte slots, conflict-free at stride 1.
 //   * accumulator layout (32x32): lane&31 = channel, so every epilogue store instruction writes two
 //     full 128-byte channel runs.
+#include <algorithm>
 #include "common.h"
 
 namespace pivlfn {
@@ -262,31 +263,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(const ConvParams p)
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bq[n][j], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[n][j], a[m][j], acc[m][n], 0, 0, 0);   // A = channels, B = pixels
             }
         }
         __syncthreads();       // all waves done with this chunk's LDS image before it is overwritten
     }
 #undef CONV2_LOAD
 
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int ch = n0 + n * 32 + row;
-        if (ch >= p.cout_store) continue;
-        const float bias = p.bias[ch];
+    // Epilogue.  With A = weights and B = pixels the accumulator tile is D[channel][pixel]: lane&31 = pixel, and registers
+    // 4g..4g+3 hold channels 8g + 4*hh + {0,1,2,3} -- four consecutive channels per lane, so bias / residual / output move
+    // as 16-byte vectors: 32 stores per thread for a 64x128 wave tile instead of 128, and a quarter of the address math.
+    {
+        const int ox = x0 + row;
+        const bool interior = x0 + 32 <= p.Wo && y0 + TH <= p.Ho && n0 + BN <= p.cout_store;   // workgroup-uniform fast path
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = y0 + wave * MT + m;
-            if (oy >= p.Ho) continue;
+            const bool pix_ok = interior || (oy < p.Ho && ox < p.Wo);
+            const size_t pix = (size_t)(b * p.Ho + (oy < p.Ho ? oy : 0)) * p.Wo + (ox < p.Wo ? ox : 0);
+            float *orow = p.out + pix * p.out_stride;
+            const float *rrow = p.res ? p.res + pix * p.res_stride : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (ox >= p.Wo) continue;
-                const size_t pix = (size_t)(b * p.Ho + oy) * p.Wo + ox;
-                float v = acc[m][n][r] + bias;
-                if (p.res) v += p.res[pix * p.res_stride + ch];
-                if (p.lrelu) v = lrelu01(v);
-                p.out[pix * p.out_stride + ch] = v;
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n0 + n * 32 + 8 * g + 4 * hh;
+                    if (!pix_ok || (!interior && ch >= p.cout_store)) continue;
+                    f32x4 v = {acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                    v += *reinterpret_cast<const f32x4 *>(p.bias + ch);
+                    if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + ch);
+                    if (p.lrelu) {
+                        v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                    }
+                    *reinterpret_cast<f32x4 *>(orow + ch) = v;
+                }
             }
         }
     }
@@ -354,6 +364,7 @@ static int launch_conv2(const ConvParams &p, hipStream_t st)
     }
 #undef PICK
 }
+
 
 template <int MT, int NT>
 static int launch_t(const ConvParams &p, hipStream_t st)
