@@ -89,7 +89,8 @@ struct ConvParams {
     int B, H, W;        // input
     int Ho, Wo;         // output
     int KH, KW, S, padY, padX;
-    int nchunk;         // K chunks of 8 input channels over all segments
+    int nchunk;         // K chunks of 8 input channels over all segments (the last one may be a 4-channel tail)
+    int tail;           // 1 when the last chunk is a 4-channel tail (last source has cload % 8 == 4)
     int lrelu;
 };
 

@@ -26,6 +26,7 @@ namespace pivlfn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int PIXP = 12;
 
@@ -144,8 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 // written to LDS after them, so the global/L2 latency hides behind the matrix work even with one workgroup per CU
 // (the small pyramid levels, where v1 spent >90% of its time waiting on exposed staging).
 // PMAX / WMAX = compile-time bounds on the 16-byte loads per thread for the patch / the weight slab.
+// (64-accumulator tiles with the small staging class fit 168 VGPRs: three workgroups per CU)
 template <int MT, int NT, int PMAX, int WMAX>
-__global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2) void conv_mfma2_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = NT * 32;
@@ -217,9 +219,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(const ConvParams p)
 
 #define CONV2_LOAD(CH)                                                                            \
     do {                                                                                          \
+        const int qoff_ = (scl - c0 <= 4) ? 0 : q4;      /* 4-channel tail: both quads fetch the same 16 bytes */ \
         _Pragma("unroll") for (int i = 0; i < PMAX; ++i) {                                        \
             f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                       \
-            if (poff[i] >= 0 && c0 + q4 < scl) v = *reinterpret_cast<const f32x4 *>(sp + (size_t)poff[i] * sst + c0 + q4); \
+            if (poff[i] >= 0) v = *reinterpret_cast<const f32x4 *>(sp + (size_t)poff[i] * sst + c0 + qoff_); \
             pr[i] = v;                                                                            \
         }                                                                                         \
         const f32x4 *wc_ = wsrc + (size_t)(CH)*wchunk;                                            \
@@ -227,8 +230,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(const ConvParams p)
             if (woff[i] >= 0) wr[i] = wc_[woff[i]];                                               \
     } while (0)
 
+    // K loop.  A source whose channel count is 4 (mod 8) ends in a half chunk; the packer only allows that for the LAST
+    // source, so the tail is peeled: the hot loop below stays branch-free, and the tail contracts its 4 channels with two
+    // MFMAs per tap (k = {j, 2+j}; staged as [c0 c1 c2 c3 | c2 c3 0 0] so both lane halves read their pair at j = 0, 1).
+    const int nfull = p.nchunk - p.tail;
     CONV2_LOAD(0);
-    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    for (int chunk = 0; chunk < nfull; ++chunk) {
         // registers -> LDS (waits for the loads of this chunk)
 #pragma unroll
         for (int i = 0; i < PMAX; ++i)
@@ -267,6 +274,38 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(const ConvParams p)
             }
         }
         __syncthreads();       // all waves done with this chunk's LDS image before it is overwritten
+    }
+    if (p.tail) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i)
+            if (plds[i] >= 0) {
+                f32x4 v = pr[i];
+                if (q4) v = f32x4{v[2], v[3], 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(patch + plds[i]) = v;
+            }
+#pragma unroll
+        for (int i = 0; i < WMAX; ++i)
+            if (woff[i] >= 0) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+        __syncthreads();
+        int tap = 0;
+        for (int ky = 0; ky < p.KH; ++ky) {
+            for (int kx = 0; kx < p.KW; ++kx, ++tap) {
+                const int toff = (ky * PW + kx) * PIXP;
+                f32x2 a[MT], bq[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x2 *>(patch + abase[m] + toff);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    bq[n] = *reinterpret_cast<const f32x2 *>(wts + tap * 2 * BN * 4 + bbase + n * 128);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[n][j], a[m][j], acc[m][n], 0, 0, 0);
+            }
+        }
     }
 #undef CONV2_LOAD
 
@@ -397,6 +436,7 @@ int launch_conv(const ConvParams &p, hipStream_t st)
         const int rc = launch_conv2(p, st);
         if (rc >= 0) return rc;
     }
+    PIV_REQUIRE(!p.tail, "conv: this layer's weights are packed with a 4-channel tail chunk, which only the v2 kernel understands");
     int nt;
     if (p.cout_pad % 128 == 0) nt = 4;
     else if (p.cout_pad % 96 == 0) nt = 3;

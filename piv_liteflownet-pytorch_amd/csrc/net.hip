@@ -17,7 +17,7 @@ static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 
 struct ConvW {
     float *wpk = nullptr, *bias = nullptr;
-    int cout = 0, cout_pad = 0, KH = 0, KW = 0, nchunk = 0;
+    int cout = 0, cout_pad = 0, KH = 0, KW = 0, nchunk = 0, tail = 0;
 };
 
 struct LevelW {
@@ -87,10 +87,11 @@ static const pivlfn_tensor *find(const TMap &m, const std::string &name, int d0,
     return t;
 }
 
-struct SegDef { int creal, cload; };
+struct SegDef { int creal, cload; int coff = -1; };   // coff: first input channel of this source in the OIHW weight (-1 = running offset)
 
 // OIHW weights -> [chunk][tap][half][cout_pad][4]; chunk = 8 staged input channels of one source.
-// Element (chunk, tap, h, n, j) multiplies staged channel 8*chunk_in_seg + 4*h + j of that source.
+// Element (chunk, tap, h, n, j) multiplies staged channel 8*chunk_in_seg + 4*h + j of that source; when only one quad
+// of the source is left (its 4-channel tail) the chunk is a half chunk: channels 2*h + j, j < 2 (two MFMAs per tap).
 static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, int cout, int cin, int kh, int kw,
                      const std::vector<SegDef> &segs, ConvW *out)
 {
@@ -102,22 +103,31 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
     if (creal != cin) { set_error("internal: segment channels %d != cin %d for %s", creal, cin, name.c_str()); return PIVLFN_ERR_WEIGHTS; }
     const int taps = kh * kw, cp = rup(cout, 32);
     std::vector<float> pk((size_t)nchunk * taps * 2 * cp * 4, 0.f), bias(cp, 0.f);
-    int chunk = 0, coff = 0;
-    for (auto &s : segs) {
-        for (int c0 = 0; c0 < s.cload; c0 += 8, ++chunk)
+    int chunk = 0, run = 0, tail = 0;
+    for (size_t si = 0; si < segs.size(); ++si) {
+        const SegDef &s = segs[si];
+        const int coff = s.coff >= 0 ? s.coff : run;
+        if (s.cload % 8 == 4 && si + 1 != segs.size()) {
+            set_error("internal: only the last source of %s may end in a 4-channel tail", name.c_str());
+            return PIVLFN_ERR_WEIGHTS;
+        }
+        for (int c0 = 0; c0 < s.cload; c0 += 8, ++chunk) {
+            const bool half = s.cload - c0 <= 4;     // 4-channel tail: lane half h holds channels {2h, 2h+1} in slots j = 0, 1
+            if (half) tail = 1;
             for (int t = 0; t < taps; ++t)
                 for (int h = 0; h < 2; ++h)
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = c0 + 4 * h + j;
+                    for (int j = 0; j < (half ? 2 : 4); ++j) {
+                        const int c = c0 + (half ? 2 * h : 4 * h) + j;
                         if (c >= s.creal) continue;
                         for (int n = 0; n < cout; ++n)
                             pk[((((size_t)chunk * taps + t) * 2 + h) * cp + n) * 4 + j] =
                                 w->data[((size_t)n * cin + coff + c) * taps + t];
                     }
-        coff += s.creal;
+        }
+        run += s.creal;
     }
     for (int n = 0; n < cout; ++n) bias[n] = b->data[n];
-    out->cout = cout; out->cout_pad = cp; out->KH = kh; out->KW = kw; out->nchunk = nchunk;
+    out->cout = cout; out->cout_pad = cp; out->KH = kh; out->KW = kw; out->nchunk = nchunk; out->tail = tail;
     int rc = upload(net, pk, &out->wpk);
     if (rc) return rc;
     return upload(net, bias, &out->bias);
@@ -228,7 +238,7 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
                           pr = "NetE_R." + std::to_string(i) + ".";
         if (L != 6) TRY(pack_dw(net, m, pm + "upConv_M.weight", 2, 4, &lw.upconv));
         if (L < 4) TRY(pack_dw(net, m, pm + "upCorr_M.weight", 49, 56, &lw.upcorr));
-        TRY(pack_conv(net, m, pm + "conv_M.0", 128, 49, 3, 3, {{49, 56}}, &lw.M[0]));
+        TRY(pack_conv(net, m, pm + "conv_M.0", 128, 49, 3, 3, {{49, 52}}, &lw.M[0]));
         TRY(pack_conv(net, m, pm + "conv_M.2", 64, 128, 3, 3, {{128, 128}}, &lw.M[1]));
         TRY(pack_conv(net, m, pm + "conv_M.4", 32, 64, 3, 3, {{64, 64}}, &lw.M[2]));
         TRY(pack_conv(net, m, pm + "conv_M.6", 2, 32, k, k, {{32, 32}}, &lw.M[3]));
@@ -240,7 +250,7 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
         TRY(pack_head(net, m, ps + "conv_S.6", k, &lw.headS, lw.hbS));
         const int cfr = L < 5 ? 128 : C_FEAT[L];
         if (L < 5) TRY(pack_conv(net, m, pr + "moduleFeat.0", 128, C_FEAT[L], 1, 1, {{C_FEAT[L], C_FEAT[L]}}, &lw.feat));
-        TRY(pack_conv(net, m, pr + "conv_R.0", 128, 3 + cfr, 3, 3, {{3, 4}, {cfr, cfr}}, &lw.R[0]));
+        TRY(pack_conv(net, m, pr + "conv_R.0", 128, 3 + cfr, 3, 3, {{cfr, cfr, 3}, {3, 4, 0}}, &lw.R[0]));   // reference order is [norm, rm, feat] (:280)
         TRY(pack_conv(net, m, pr + "conv_R.2", 128, 128, 3, 3, {{128, 128}}, &lw.R[1]));
         TRY(pack_conv(net, m, pr + "conv_R.4", 64, 128, 3, 3, {{128, 128}}, &lw.R[2]));
         TRY(pack_conv(net, m, pr + "conv_R.6", 64, 64, 3, 3, {{64, 64}}, &lw.R[3]));
@@ -313,7 +323,7 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
     p.B = B; p.H = H; p.W = W; p.KH = c->cw.KH; p.KW = c->cw.KW; p.S = stride; p.padY = pad_y; p.padX = pad_x;
     p.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
     p.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
-    p.nchunk = c->cw.nchunk; p.lrelu = leaky;
+    p.nchunk = c->cw.nchunk; p.tail = c->cw.tail; p.lrelu = leaky;
     return launch_conv(p, st);
 }
 
@@ -397,7 +407,7 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
     p.KH = cw.KH; p.KW = cw.KW; p.S = S; p.padY = padY; p.padX = padX;
     p.Ho = (H + 2 * padY - cw.KH) / S + 1;
     p.Wo = (W + 2 * padX - cw.KW) / S + 1;
-    p.nchunk = cw.nchunk; p.lrelu = lrelu;
+    p.nchunk = cw.nchunk; p.tail = cw.tail; p.lrelu = lrelu;
     return launch_conv(p, st);
 }
 
@@ -472,7 +482,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             RUN(launch_dwconvT(bf.corr, lw.upcorr, bf.corr_up, B, hh / 2, ww / 2, 49, 56, 56, 56, st));
             cin = bf.corr_up;
         }
-        RUN(conv(lw.M[0], {{cin, 56, 56}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.M[0], {{cin, 52, 56}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.M[1], {{bf.t128a, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.M[2], {{bf.t64a, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         if (g_knob[1] & 1)    // A/B: heads on the matrix cores (30 of 32 output columns wasted)
@@ -498,7 +508,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             fr = bf.featR;
             cfr = 128;
         }
-        RUN(conv(lw.R[0], {{bf.misc4, 4, 4}, {fr, cfr, cfr}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.R[0], {{fr, cfr, cfr}, {bf.misc4, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.R[1], {{bf.t128a, 128, 128}}, bf.t128b, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.R[2], {{bf.t128b, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.R[3], {{bf.t64a, 64, 64}}, bf.t64b, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
