@@ -374,6 +374,7 @@ static int launch_conv2(const ConvParams &p, hipStream_t st)
         if (p.cout_pad % (cand * 32)) continue;
         if (px_blocks1 * (p.cout_pad / (cand * 32)) >= 256 || cand == 1) { nt = cand; break; }
     }
+    if ((g_knob[1] & 8) && nt == 4) nt = 2;              // A/B: 64-channel N tiles (three workgroups per CU) for 128-channel layers
     int mt = (px_blocks1 / 2) * (p.cout_pad / (nt * 32)) >= 512 ? 2 : 1;
     auto need = [&](int mt_, int nt_, int &pm, int &wm) {
         const int PH = (4 * mt_ - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
