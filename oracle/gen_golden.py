@@ -13,7 +13,7 @@ Nothing from the reference is written to disk: fixtures hold inputs (seeded uint
 seeded random tensors) and the reference's numeric outputs only.  Weights are NOT stored: both sides
 regenerate them from `pivlfn.synth.generate_weights(model, seed)`.
 
-Usage:  python oracle/gen_golden.py            (writes tests/golden/, prints the pin report)
+Usage:  python oracle/gen_golden.py [--only-v2]   (writes tests/golden/, prints the pin report)
 """
 from __future__ import annotations
 
@@ -57,8 +57,60 @@ def relerr(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
 
 
+def main_v2(ref):
+    """LiteFlowNet2 backbones (`--version 2`, src/models.py:373-716): layout pin + end-to-end fixtures."""
+    report = {}
+    e2e = {}
+    for model, factory in (("piv2", ref.piv_liteflownet), ("hui2", ref.hui_liteflownet)):
+        sd = factory(version=2).state_dict()
+        spec = [[k, list(v.shape)] for k, v in sd.items()]
+        mine = [[k, list(v)] for k, v in synth.state_dict_spec(model).items()]
+        assert spec == mine, f"state dict layout mismatch for {model}"
+        with open(os.path.join(GOLD, f"state_dict_spec_{model}.json"), "w") as f:
+            json.dump(spec, f)
+        report[f"spec_{model}"] = {"tensors": len(spec), "params": int(sum(int(np.prod(s)) for _, s in spec))}
+    for model, B, H, W, seed in [("piv2", 1, 64, 64, 61), ("piv2", 2, 96, 160, 71), ("hui2", 1, 64, 96, 81)]:
+        wts = synth.generate_weights(model, seed=0)
+        factory = ref.piv_liteflownet if model == "piv2" else ref.hui_liteflownet
+        net = factory(wts, version=2)
+        fr1, fr2 = [], []
+        for b in range(B):
+            a, c, _ = synth.particle_pair(H, W, seed + b)
+            fr1.append(a); fr2.append(c)
+        fr1 = np.stack(fr1); fr2 = np.stack(fr2)
+        i1 = torch.from_numpy(np.stack([synth.to_input(a) for a in fr1]))
+        i2 = torch.from_numpy(np.stack([synth.to_input(a) for a in fr2]))
+        with torch.no_grad():
+            ref.backwarp_tensorGrid.clear()
+            net.eval()
+            out_ref = net(i1.clone(), i2.clone()).numpy()
+            ref.backwarp_tensorGrid.clear()
+            net.train()
+            lv_ref = net(i1.clone(), i2.clone())[:-1]          # LiteFlowNet2 appends the upsampled flow in training mode (:709-712)
+            net.eval()
+            out_orc, lv_orc = orc.make_net(model, wts, torch.float32, corr="c").forward(i1, i2, return_levels=True)
+        tag = f"{model}_{B}x{H}x{W}"
+        bit = bool(np.array_equal(out_orc.numpy(), out_ref))
+        assert relerr(out_orc.numpy(), out_ref) < 1e-5, tag
+        e2e[f"{tag}_img1"] = fr1; e2e[f"{tag}_img2"] = fr2; e2e[f"{tag}_flow"] = out_ref
+        for j, (m, s_, r) in enumerate(lv_ref):
+            e2e[f"{tag}_lv{j}_M"] = m.numpy(); e2e[f"{tag}_lv{j}_S"] = s_.numpy(); e2e[f"{tag}_lv{j}_R"] = r.numpy()
+            for a, bb in zip((m, s_, r), lv_orc[j]):
+                assert relerr(bb.numpy(), a.numpy()) < 1e-4
+        report[f"e2e_{tag}"] = {"bit_identical": bit, "max_abs_flow_px": float(np.abs(out_ref).max()), "seed": seed,
+                                "out_shape": list(out_ref.shape)}
+    np.savez_compressed(os.path.join(GOLD, "e2e_v2_cases.npz"), **e2e)
+    with open(os.path.join(GOLD, "pin_report_v2.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print(json.dumps(report, indent=1))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-v2" in sys.argv:
+        torch.set_num_threads(8)
+        main_v2(import_reference())
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
@@ -166,6 +218,7 @@ def main():
     with open(os.path.join(GOLD, "pin_report.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report, indent=1))
+    main_v2(ref)
 
 
 if __name__ == "__main__":

@@ -174,6 +174,15 @@ class OracleNet:
         y = F.conv2d(x, self.w[name + ".weight"], self.w.get(name + ".bias"), stride=stride, padding=pad)
         return _lrelu(y) if act else y
 
+    def _stack(self, prefix, x, k):
+        """conv_M / conv_S: 3x3 + LeakyReLU layers at indices 0, 2, ... then the k x k flow head without activation
+        (v1: 3 hidden layers, src/models.py:154-163, 197-207; LiteFlowNet2: 5, :487-500, 534-548)."""
+        j = 0
+        while f"{prefix}{j + 2}.weight" in self.w:
+            x = self._conv(f"{prefix}{j}", x, 1, 1)
+            j += 2
+        return self._conv(f"{prefix}{j}", x, 1, k // 2, act=False)
+
     def _corr(self, f1, f2, s):
         if self.corr == "c":
             return torch.from_numpy(correlation_c(f1.numpy(), f2.numpy(), s))
@@ -201,22 +210,14 @@ class OracleNet:
         else:
             corr = F.conv_transpose2d(_lrelu(self._corr(f1, f2, 2)), self.w[p + "upCorr_M.weight"], None,
                                       stride=2, padding=1, groups=49)
-        k = K_LEVEL[L]
-        x = self._conv(p + "conv_M.0", corr, 1, 1)
-        x = self._conv(p + "conv_M.2", x, 1, 1)
-        x = self._conv(p + "conv_M.4", x, 1, 1)
-        x = self._conv(p + "conv_M.6", x, 1, k // 2, act=False)
+        x = self._stack(p + "conv_M.", corr, K_LEVEL[L])
         return x + (xflow if xflow is not None else 0.0)
 
     # -- Subpixel: src/models.py:209-217 ------------------------------------------------------------
     def subpixel(self, i, L, f1, f2, xflow):
         p = f"NetE_S.{i}."
         f2 = backwarp(f2, xflow * self.scale[L])
-        k = K_LEVEL[L]
-        x = self._conv(p + "conv_S.0", torch.cat([f1, f2, xflow], 1), 1, 1)
-        x = self._conv(p + "conv_S.2", x, 1, 1)
-        x = self._conv(p + "conv_S.4", x, 1, 1)
-        x = self._conv(p + "conv_S.6", x, 1, k // 2, act=False)
+        x = self._stack(p + "conv_S.", torch.cat([f1, f2, xflow], 1), K_LEVEL[L])
         return x + xflow
 
     # -- Regularization: src/models.py:274-303 --------------------------------------------------------
@@ -282,7 +283,11 @@ class OracleNet:
 
 
 def make_net(model: str, weights, dtype=torch.float32, corr: str = "torch") -> OracleNet:
-    """Mirrors the factories src/models.py:719-766 (version 1 only)."""
+    """Mirrors the factories src/models.py:719-766; 'hui2' / 'piv2' = the LiteFlowNet2 backbones (version=2)."""
+    if model == "hui2":
+        return OracleNet(weights, 40.0, 3, (0.411618, 0.434631, 0.454253, 0.410782, 0.433645, 0.452793), dtype, corr)
+    if model == "piv2":
+        return OracleNet(weights, 10.0, 2, (0.194286, 0.190633, 0.191766, 0.194220, 0.190595, 0.191701), dtype, corr)
     if model == "hui":
         return OracleNet(weights, 40.0, 2, (0.411618, 0.434631, 0.454253, 0.410782, 0.433645, 0.452793), dtype, corr)
     if model == "piv":

@@ -22,7 +22,7 @@ struct ConvW {
 
 struct LevelW {
     float *upconv = nullptr, *upcorr = nullptr;    // depthwise k4 weights [16 taps][C4]
-    ConvW M[4], S[4], R[6], feat, dist0, dist1;
+    ConvW M[6], S[6], R[6], feat, dist0, dist1;   // M/S: nstack hidden 3x3 layers, then the k x k head at index nstack
     float *headM = nullptr, *headS = nullptr;      // VALU flow-head weights [k*k][8][2][4]
     float hbM[2] = {0.f, 0.f}, hbS[2] = {0.f, 0.f};
     float *wx = nullptr, *wy = nullptr;
@@ -43,6 +43,8 @@ struct pivlfn_conv {
 struct pivlfn_net {
     float scale[7];
     int lowest;
+    int nstack = 3;                // hidden conv_M / conv_S layers: 3 = LiteFlowNet (src/models.py:154-163), 5 = LiteFlowNet2 (:487-500)
+    int width[5] = {128, 64, 32, 0, 0};
     float mean[6];
     pivlfn::ConvW netc[10];
     pivlfn::ConvW ext[3];          // index by level (1,2)
@@ -216,6 +218,11 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
     net->lowest = lowest;
     for (int L = 0; L < 7; ++L) net->scale[L] = starting_scale / (float)(1 << L);     // src/models.py:61-63
     for (int i = 0; i < 6; ++i) net->mean[i] = mean[i];
+    if (m.count("NetE_M.0.conv_M.10.weight")) {          // LiteFlowNet2 layout: five hidden layers per stack
+        net->nstack = 5;
+        const int w2[5] = {128, 128, 96, 64, 32};
+        for (int j = 0; j < 5; ++j) net->width[j] = w2[j];
+    }
 #define TRY(expr) do { int _rc = (expr); if (_rc) { net_destroy(net); return _rc; } } while (0)
     // NetC (src/models.py:70-106); conv1 reads the 4-lane padded image
     struct { const char *name; int cout, cin, k; } nc[10] = {
@@ -238,16 +245,30 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
                           pr = "NetE_R." + std::to_string(i) + ".";
         if (L != 6) TRY(pack_dw(net, m, pm + "upConv_M.weight", 2, 4, &lw.upconv));
         if (L < 4) TRY(pack_dw(net, m, pm + "upCorr_M.weight", 49, 56, &lw.upcorr));
-        TRY(pack_conv(net, m, pm + "conv_M.0", 128, 49, 3, 3, {{49, 52}}, &lw.M[0]));
-        TRY(pack_conv(net, m, pm + "conv_M.2", 64, 128, 3, 3, {{128, 128}}, &lw.M[1]));
-        TRY(pack_conv(net, m, pm + "conv_M.4", 32, 64, 3, 3, {{64, 64}}, &lw.M[2]));
-        TRY(pack_conv(net, m, pm + "conv_M.6", 2, 32, k, k, {{32, 32}}, &lw.M[3]));
-        TRY(pack_head(net, m, pm + "conv_M.6", k, &lw.headM, lw.hbM));
-        TRY(pack_conv(net, m, ps + "conv_S.0", 128, 2 * cm + 2, 3, 3, {{cm, cm}, {cm, cm}, {2, 4}}, &lw.S[0]));
-        TRY(pack_conv(net, m, ps + "conv_S.2", 64, 128, 3, 3, {{128, 128}}, &lw.S[1]));
-        TRY(pack_conv(net, m, ps + "conv_S.4", 32, 64, 3, 3, {{64, 64}}, &lw.S[2]));
-        TRY(pack_conv(net, m, ps + "conv_S.6", 2, 32, k, k, {{32, 32}}, &lw.S[3]));
-        TRY(pack_head(net, m, ps + "conv_S.6", k, &lw.headS, lw.hbS));
+        {
+            int cin = 49;
+            for (int j = 0; j < net->nstack; ++j) {
+                const int wd = net->width[j];
+                const std::string nm = pm + "conv_M." + std::to_string(2 * j);
+                if (j == 0) TRY(pack_conv(net, m, nm, wd, 49, 3, 3, {{49, 52}}, &lw.M[0]));
+                else TRY(pack_conv(net, m, nm, wd, cin, 3, 3, {{cin, cin}}, &lw.M[j]));
+                cin = wd;
+            }
+            const std::string hm = pm + "conv_M." + std::to_string(2 * net->nstack);
+            TRY(pack_conv(net, m, hm, 2, 32, k, k, {{32, 32}}, &lw.M[net->nstack]));
+            TRY(pack_head(net, m, hm, k, &lw.headM, lw.hbM));
+            cin = 2 * cm + 2;
+            for (int j = 0; j < net->nstack; ++j) {
+                const int wd = net->width[j];
+                const std::string nm = ps + "conv_S." + std::to_string(2 * j);
+                if (j == 0) TRY(pack_conv(net, m, nm, wd, 2 * cm + 2, 3, 3, {{cm, cm}, {cm, cm}, {2, 4}}, &lw.S[0]));
+                else TRY(pack_conv(net, m, nm, wd, cin, 3, 3, {{cin, cin}}, &lw.S[j]));
+                cin = wd;
+            }
+            const std::string hs = ps + "conv_S." + std::to_string(2 * net->nstack);
+            TRY(pack_conv(net, m, hs, 2, 32, k, k, {{32, 32}}, &lw.S[net->nstack]));
+            TRY(pack_head(net, m, hs, k, &lw.headS, lw.hbS));
+        }
         const int cfr = L < 5 ? 128 : C_FEAT[L];
         if (L < 5) TRY(pack_conv(net, m, pr + "moduleFeat.0", 128, C_FEAT[L], 1, 1, {{C_FEAT[L], C_FEAT[L]}}, &lw.feat));
         TRY(pack_conv(net, m, pr + "conv_R.0", 128, 3 + cfr, 3, 3, {{cfr, cfr, 3}, {3, 4, 0}}, &lw.R[0]));   // reference order is [norm, rm, feat] (:280)
@@ -482,22 +503,43 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             RUN(launch_dwconvT(bf.corr, lw.upcorr, bf.corr_up, B, hh / 2, ww / 2, 49, 56, 56, 56, st));
             cin = bf.corr_up;
         }
-        RUN(conv(lw.M[0], {{cin, 52, 56}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.M[1], {{bf.t128a, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.M[2], {{bf.t64a, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        const float *hid = nullptr;       // output of the last hidden layer (32 channels)
+        {
+            const float *src = cin;
+            int cprev = 0;
+            for (int j = 0; j < net->nstack; ++j) {
+                const int wd = net->width[j];
+                float *dst = (j & 1) ? bf.t128b : bf.t128a;
+                if (j == 0) RUN(conv(lw.M[0], {{src, 52, 56}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+                else RUN(conv(lw.M[j], {{src, cprev, cprev}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+                src = dst;
+                cprev = wd;
+            }
+            hid = src;
+        }
         if (g_knob[1] & 1)    // A/B: heads on the matrix cores (30 of 32 output columns wasted)
-            RUN(conv(lw.M[3], {{bf.t32a, 32, 32}}, bf.flowM, 4, 4, fup, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+            RUN(conv(lw.M[net->nstack], {{hid, 32, 32}}, bf.flowM, 4, 4, fup, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
         else
-            RUN(launch_conv_head(bf.t32a, lw.headM, lw.hbM[0], lw.hbM[1], fup, bf.flowM, B, hh, ww, k, st));
+            RUN(launch_conv_head(hid, lw.headM, lw.hbM[0], lw.hbM[1], fup, bf.flowM, B, hh, ww, k, st));
         // ---- Subpixel (:209-217)
         RUN(launch_backwarp_nhwc(f2m, bf.flowM, sc, bf.f2w, B, hh, ww, cm, st));
-        RUN(conv(lw.S[0], {{f1m, cm, cm}, {bf.f2w, cm, cm}, {bf.flowM, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.S[1], {{bf.t128a, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.S[2], {{bf.t64a, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        {
+            const float *src = nullptr;
+            int cprev = 0;
+            for (int j = 0; j < net->nstack; ++j) {
+                const int wd = net->width[j];
+                float *dst = (j & 1) ? bf.t128b : bf.t128a;
+                if (j == 0) RUN(conv(lw.S[0], {{f1m, cm, cm}, {bf.f2w, cm, cm}, {bf.flowM, 4, 4}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+                else RUN(conv(lw.S[j], {{src, cprev, cprev}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+                src = dst;
+                cprev = wd;
+            }
+            hid = src;
+        }
         if (g_knob[1] & 1)
-            RUN(conv(lw.S[3], {{bf.t32a, 32, 32}}, bf.flowS, 4, 4, bf.flowM, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
+            RUN(conv(lw.S[net->nstack], {{hid, 32, 32}}, bf.flowS, 4, 4, bf.flowM, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
         else
-            RUN(launch_conv_head(bf.t32a, lw.headS, lw.hbS[0], lw.hbS[1], bf.flowM, bf.flowS, B, hh, ww, k, st));
+            RUN(launch_conv_head(hid, lw.headS, lw.hbS[0], lw.hbS[1], bf.flowM, bf.flowS, B, hh, ww, k, st));
         // ---- Regularization (:274-303); note it takes the RAW NetC feature (:361)
         RUN(launch_flow_mean(bf.flowS, bf.partial, bf.mean, B, hh * ww, st));
         RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, sc, bf.misc4, B, hh, ww, st));

@@ -6,8 +6,8 @@ the thin Python host side that mirrors the reference's names and argument meanin
 fallback: importing works anywhere, but every op raises if the library or a GPU is missing.
 """
 from .correlation import FunctionCorrelation, ModuleCorrelation          # noqa: F401
-from .models import LiteFlowNet, Network, backwarp, hui_liteflownet, piv_liteflownet  # noqa: F401
+from .models import LiteFlowNet, LiteFlowNet2, Network, backwarp, hui_liteflownet, piv_liteflownet  # noqa: F401
 from .inference import estimate                                          # noqa: F401
 
-__all__ = ["FunctionCorrelation", "ModuleCorrelation", "LiteFlowNet", "Network", "backwarp",
+__all__ = ["FunctionCorrelation", "ModuleCorrelation", "LiteFlowNet", "LiteFlowNet2", "Network", "backwarp",
            "hui_liteflownet", "piv_liteflownet", "estimate"]

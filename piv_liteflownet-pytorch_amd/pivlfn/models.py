@@ -14,7 +14,8 @@ Differences, all deliberate and documented in DESIGN.md:
     caller passes temporaries, inference.py:46-54);
   * training mode raises NotImplementedError (the reference returns per-level flows, :365-367; they are
     available for tests through `forward_levels`);
-  * version=2 (LiteFlowNet2) is not built yet and raises NotImplementedError.
+LiteFlowNet2 (src/models.py:373-716, `version=2` in the factories) is the same pipeline with five hidden layers in
+conv_M / conv_S; it shares every kernel and differs only in the state-dict layout and the default levels.
 """
 from __future__ import annotations
 
@@ -28,7 +29,7 @@ import torch
 from . import _lib
 from .synth import MODEL_CFG, state_dict_spec
 
-__all__ = ["hui_liteflownet", "piv_liteflownet", "LiteFlowNet", "Network", "backwarp"]
+__all__ = ["hui_liteflownet", "piv_liteflownet", "LiteFlowNet", "LiteFlowNet2", "Network", "backwarp"]
 
 
 def backwarp(tensorInput: torch.Tensor, tensorFlow: torch.Tensor) -> torch.Tensor:
@@ -54,6 +55,8 @@ class _Holder(torch.nn.Module):
 
 
 class LiteFlowNet(torch.nn.Module):
+    VERSION = 1
+
     def __init__(self, starting_scale: int = 40, lowest_level: int = 2,
                  rgb_mean: Union[Tuple[float, ...], List[float]] = (0.411618, 0.434631, 0.454253, 0.410782, 0.433645, 0.452793)
                  ) -> None:
@@ -66,7 +69,7 @@ class LiteFlowNet(torch.nn.Module):
         self.SCALEFACTOR = [float(starting_scale) / (2.0 ** level) for level in range(self.PLEVELS + 1)]
         self.level2use = list(range(self.lowest_level, self.PLEVELS + 1))
         gen = torch.Generator().manual_seed(0)
-        for name, shape in state_dict_spec(lowest_level=self.lowest_level).items():
+        for name, shape in state_dict_spec(lowest_level=self.lowest_level, version=self.VERSION).items():
             fan_in = (shape[1] * shape[2] * shape[3]) if len(shape) == 4 else self._fan_in_of_bias(name)
             bound = 1.0 / math.sqrt(max(1, fan_in))
             value = (torch.rand(shape, generator=gen) * 2.0 - 1.0) * bound
@@ -77,7 +80,7 @@ class LiteFlowNet(torch.nn.Module):
 
     # -- parameter tree --------------------------------------------------------------------------------
     def _fan_in_of_bias(self, name: str) -> int:
-        w = dict(state_dict_spec(lowest_level=self.lowest_level))[name[:-len("bias")] + "weight"]
+        w = dict(state_dict_spec(lowest_level=self.lowest_level, version=self.VERSION))[name[:-len("bias")] + "weight"]
         return w[1] * w[2] * w[3]
 
     def _register(self, dotted: str, param: torch.nn.Parameter) -> None:
@@ -201,13 +204,22 @@ class LiteFlowNet(torch.nn.Module):
         return ms.value, empty.value, n.value
 
 
+class LiteFlowNet2(LiteFlowNet):
+    """LiteFlowNet2 (Hui 2020), src/models.py:373-716: defaults starting_scale 40, lowest level 3 (quarter-resolution flow)."""
+    VERSION = 2
+
+    def __init__(self, starting_scale: int = 40, lowest_level: int = 3,
+                 rgb_mean: Union[Tuple[float, ...], List[float]] = (0.411618, 0.434631, 0.454253, 0.410782, 0.433645, 0.452793)
+                 ) -> None:
+        super(LiteFlowNet2, self).__init__(starting_scale, lowest_level, rgb_mean)
+
+
 def _build(model: str, params: Optional[OrderedDict], version: int) -> LiteFlowNet:
-    if version == 2:
-        raise NotImplementedError("LiteFlowNet2 (version=2, src/models.py:373-716) is not built yet")
-    if version != 1:
+    if version not in (1, 2):
         raise ValueError(f'Wrong input of model version (input = {version})! Choose between version 1 or 2 only!')
-    cfg = MODEL_CFG[model]
-    net = LiteFlowNet(starting_scale=cfg["starting_scale"], lowest_level=cfg["lowest_level"], rgb_mean=cfg["rgb_mean"])
+    cfg = MODEL_CFG[model + ("2" if version == 2 else "")]
+    cls = LiteFlowNet2 if version == 2 else LiteFlowNet
+    net = cls(starting_scale=cfg["starting_scale"], lowest_level=cfg["lowest_level"], rgb_mean=cfg["rgb_mean"])
     if params is not None:
         net.load_state_dict(params)
     return net

@@ -35,13 +35,27 @@ MODEL_CFG = {
                 rgb_mean=(0.411618, 0.434631, 0.454253, 0.410782, 0.433645, 0.452793)),
     "piv": dict(starting_scale=10.0, lowest_level=1,
                 rgb_mean=(0.173935, 0.180594, 0.192608, 0.172978, 0.179518, 0.191300)),
+    # LiteFlowNet2 backbones: src/models.py:731-732 (defaults :374-375) and :756-758
+    "hui2": dict(starting_scale=40.0, lowest_level=3,
+                 rgb_mean=(0.411618, 0.434631, 0.454253, 0.410782, 0.433645, 0.452793)),
+    "piv2": dict(starting_scale=10.0, lowest_level=2,
+                 rgb_mean=(0.194286, 0.190633, 0.191766, 0.194220, 0.190595, 0.191701)),
 }
+STACK = {1: [128, 64, 32], 2: [128, 128, 96, 64, 32]}      # hidden widths of conv_M / conv_S (src/models.py:154-163 vs :487-500)
 
 
-def state_dict_spec(model: str = "piv", lowest_level: int | None = None) -> "OrderedDict[str, Tuple[int, ...]]":
-    """Ordered name -> shape map of `LiteFlowNet.state_dict()` (src/models.py:305-317)."""
+def model_version(model: str) -> int:
+    return 2 if model.endswith("2") else 1
+
+
+def state_dict_spec(model: str = "piv", lowest_level: int | None = None, version: int | None = None
+                    ) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Ordered name -> shape map of `LiteFlowNet.state_dict()` / `LiteFlowNet2.state_dict()` (src/models.py:305-317, 651-663)."""
     if lowest_level is None:
         lowest_level = MODEL_CFG[model]["lowest_level"]
+    if version is None:
+        version = model_version(model)
+    widths = STACK[version]
     spec: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
 
     def conv(name, cout, cin, kh, kw, bias=True):
@@ -66,12 +80,18 @@ def state_dict_spec(model: str = "piv", lowest_level: int | None = None) -> "Ord
             spec[f"NetE_M.{i}.upConv_M.weight"] = (2, 1, 4, 4)
         if L < 4:
             spec[f"NetE_M.{i}.upCorr_M.weight"] = (49, 1, 4, 4)
-        conv(f"NetE_M.{i}.conv_M.0", 128, 49, 3, 3); conv(f"NetE_M.{i}.conv_M.2", 64, 128, 3, 3)
-        conv(f"NetE_M.{i}.conv_M.4", 32, 64, 3, 3); conv(f"NetE_M.{i}.conv_M.6", 2, 32, k, k)
+        cin = 49
+        for j, wd in enumerate(widths):
+            conv(f"NetE_M.{i}.conv_M.{2 * j}", wd, cin, 3, 3)
+            cin = wd
+        conv(f"NetE_M.{i}.conv_M.{2 * len(widths)}", 2, 32, k, k)
     for i, L in enumerate(levels):            # NetE_S (src/models.py:190-207)
         k = K_LEVEL[L]
-        conv(f"NetE_S.{i}.conv_S.0", 128, 2 * C_MATCH[L] + 2, 3, 3); conv(f"NetE_S.{i}.conv_S.2", 64, 128, 3, 3)
-        conv(f"NetE_S.{i}.conv_S.4", 32, 64, 3, 3); conv(f"NetE_S.{i}.conv_S.6", 2, 32, k, k)
+        cin = 2 * C_MATCH[L] + 2
+        for j, wd in enumerate(widths):
+            conv(f"NetE_S.{i}.conv_S.{2 * j}", wd, cin, 3, 3)
+            cin = wd
+        conv(f"NetE_S.{i}.conv_S.{2 * len(widths)}", 2, 32, k, k)
     for i, L in enumerate(levels):            # NetE_R (src/models.py:220-272)
         k = K_LEVEL[L]
         if L < 5:
@@ -105,14 +125,14 @@ def generate_weights_np(model: str = "piv", seed: int = 0, lowest_level: int | N
             w = _BILIN[None, None] * (1.0 + 0.05 * g.standard_normal(shape))
         elif ".moduleScale" in name:
             w = (1.0 + 0.1 * g.standard_normal(shape)) if name.endswith("weight") else 0.02 * g.standard_normal(shape)
-        elif name.endswith("conv_M.6.bias") or name.endswith("conv_S.6.bias"):
+        elif name.endswith(".bias") and shape == (2,):     # flow-head biases
             w = 0.12 * g.standard_normal(shape)
         elif name.endswith(".bias"):
             w = 0.05 * g.standard_normal(shape)
         else:
             cout, cin, kh, kw = shape
             gain = 1.4
-            if name.endswith("conv_M.6.weight") or name.endswith("conv_S.6.weight"):
+            if cout == 2 and cin == 32:      # flow heads (conv_M.6 / conv_S.6, or .10 in LiteFlowNet2)
                 gain = 1.0           # flow heads: O(0.3-1) updates in normalised flow units
             if ".conv_dist_R." in name:
                 gain = 0.9           # distances of O(1): exp(-d^2) spreads over the patch

@@ -89,8 +89,8 @@ def main(argv=None):
         weights = torch.load(args.weights, map_location="cpu")
         netname = os.path.splitext(os.path.basename(args.weights))[0]
     else:
-        weights = synth.generate_weights(args.model, 0)
-        netname = f"{args.model}-synthetic"
+        weights = synth.generate_weights(args.model + ("2" if args.version == 2 else ""), 0)
+        netname = f"{args.model}{'2' if args.version == 2 else ''}-synthetic"
     net = Network(model=args.model, params=weights, version=args.version).to(device).eval()
     total = 0
     for i, imdir in enumerate(args.input):

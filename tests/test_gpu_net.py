@@ -160,3 +160,22 @@ def test_run_py_end_to_end(tmp_path, dev):
         i2 = torch.from_numpy(synth.to_input(frames[k + 1]))[None].to(dev)
         want = pivlfn.estimate(net, i1, i2, tensor=False)
         assert got.shape == (64, 96, 2) and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tag", ["piv2_1x64x64", "piv2_2x96x160", "hui2_1x64x96"])
+def test_liteflownet2_matches_reference_golden(tag, dev):
+    """`--version 2` (LiteFlowNet2 backbones, src/models.py:373-716) against flows of the reference itself."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_v2_cases.npz"))
+    model = tag[:4]
+    net = pivlfn.Network(model=model[:3], params=synth.generate_weights(model, 0), version=2).to(dev).eval()
+    i1, i2 = _inputs(g, tag, dev)
+    flow, levels = net.forward_levels(i1, i2)
+    want = g[f"{tag}_flow"]
+    assert tuple(flow.shape) == want.shape                      # piv2: half resolution, hui2: quarter resolution
+    for j, trio in enumerate(levels):
+        for name, t in zip("MSR", trio):
+            _check(t.cpu().numpy(), g[f"{tag}_lv{j}_{name}"], f"{tag} level#{j} {name}")
+    _check(flow.cpu().numpy(), want, tag)
+    full = pivlfn.estimate(net, i1, i2, tensor=True)
+    assert tuple(full.shape) == (i1.shape[0], 2, i1.shape[2], i1.shape[3])

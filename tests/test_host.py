@@ -23,11 +23,11 @@ def test_public_names_match_reference_surface():
     assert inference.estimate is pivlfn.estimate
 
 
-@pytest.mark.parametrize("model", ["piv", "hui"])
+@pytest.mark.parametrize("model", ["piv", "hui", "piv2", "hui2"])
 def test_state_dict_roundtrip_strict(model):
     spec = json.load(open(os.path.join(GOLD, f"state_dict_spec_{model}.json")))
     wts = synth.generate_weights(model, seed=3)
-    net = pivlfn.Network(model=model, params=wts)
+    net = pivlfn.Network(model=model[:3], params=wts, version=2 if model.endswith("2") else 1)
     sd = net.state_dict()
     assert [[k, list(v.shape)] for k, v in sd.items()] == spec
     for k in wts:
@@ -45,8 +45,9 @@ def test_factories_configure_like_reference():
     assert p.MEAN[0] == [0.173935, 0.180594, 0.192608] and h.MEAN[1] == [0.410782, 0.433645, 0.452793]
     with pytest.raises(ValueError):
         pivlfn.piv_liteflownet(version=3)
-    with pytest.raises(NotImplementedError):
-        pivlfn.piv_liteflownet(version=2)
+    p2, h2 = pivlfn.piv_liteflownet(version=2), pivlfn.hui_liteflownet(version=2)      # src/models.py:731-732, 756-758
+    assert isinstance(p2, pivlfn.LiteFlowNet2) and p2.lowest_level == 2 and h2.lowest_level == 3
+    assert p2.SCALEFACTOR[1] == 5.0 and p2.MEAN[0] == [0.194286, 0.190633, 0.191766]
     with pytest.raises(ValueError):
         pivlfn.Network(model="foo")
 

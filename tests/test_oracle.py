@@ -98,6 +98,22 @@ def test_oracle_end_to_end_matches_reference_flows(gold):
         assert i1.min() >= 0.0                      # oracle does not mutate its inputs
 
 
+def test_oracle_liteflownet2_matches_reference_flows():
+    g = np.load(os.path.join(GOLD, "e2e_v2_cases.npz"))
+    rep = json.load(open(os.path.join(GOLD, "pin_report_v2.json")))
+    assert all(v["bit_identical"] for k, v in rep.items() if k.startswith("e2e_"))
+    for model, tag in (("piv2", "piv2_1x64x64"), ("hui2", "hui2_1x64x96")):
+        net = orc.make_net(model, synth.generate_weights(model, 0), corr="c")
+        i1, i2 = _inputs(g, tag)
+        with torch.no_grad():
+            out = net.forward(i1, i2).numpy()
+        assert out.shape == g[f"{tag}_flow"].shape
+        assert rel(out, g[f"{tag}_flow"]) < 1e-5
+    for model in ("piv2", "hui2"):
+        spec = json.load(open(os.path.join(GOLD, f"state_dict_spec_{model}.json")))
+        assert [[k, list(v)] for k, v in synth.state_dict_spec(model).items()] == spec
+
+
 def test_oracle_estimate_non_multiple_of_32(gold):
     g = gold["e2e_cases"]
     net = orc.make_net("piv", synth.generate_weights("piv", 0), corr="c")
