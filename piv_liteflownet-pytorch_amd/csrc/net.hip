@@ -50,6 +50,9 @@ struct pivlfn_net {
     pivlfn::ConvW ext[3];          // index by level (1,2)
     pivlfn::LevelW lv[7];
     std::vector<void *> allocs;
+    // side stream for the flow-independent 1x1 convs (NetC_ext, moduleFeat): they overlap the latency-bound coarse levels
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // measurement hooks
     int prof_level = 0;
     std::vector<hipEvent_t> ev;
@@ -167,6 +170,9 @@ int net_destroy(pivlfn_net *net)
     if (!net) return PIVLFN_OK;
     for (void *p : net->allocs) (void)hipFree(p);
     for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    for (hipEvent_t e : net->ev_join) if (e) (void)hipEventDestroy(e);
+    if (net->side) (void)hipStreamDestroy(net->side);
     delete net;
     return PIVLFN_OK;
 }
@@ -293,6 +299,17 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
         lw.by = by->data[0];
     }
 #undef TRY
+    if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        set_error("create: side stream / event creation failed");
+        net_destroy(net);
+        return PIVLFN_ERR_HIP;
+    }
+    for (int L = lowest; L <= 6; ++L)
+        if (hipEventCreateWithFlags(&net->ev_join[L], hipEventDisableTiming) != hipSuccess) {
+            set_error("create: event creation failed");
+            net_destroy(net);
+            return PIVLFN_ERR_HIP;
+        }
     *out = net;
     return PIVLFN_OK;
 }
@@ -369,7 +386,7 @@ struct Plan {
 struct Buffers {
     float *img[7], *feat[7], *ext[3], *sa, *sb;
     float *flowA, *flowB, *flow_up, *flowM, *flowS, *corr, *corr_up, *t128a, *t128b, *t64a, *t64b, *t32a, *t32b,
-        *f2w, *featR, *misc4, *d1, *dist, *partial, *mean;
+        *f2w, *featR[7], *misc4, *d1, *dist, *partial, *mean;
 };
 
 static void plan(const pivlfn_net *net, int B, int H, int W, Plan &pl, Buffers &bf)
@@ -393,7 +410,7 @@ static void plan(const pivlfn_net *net, int B, int H, int W, Plan &pl, Buffers &
     bf.t64a = pl.take(px * 64); bf.t64b = pl.take(px * 64);
     bf.t32a = pl.take(px * 32); bf.t32b = pl.take(px * 32);
     bf.f2w = pl.take(f2w);
-    bf.featR = pl.take(px * 128);
+    for (int L = 1; L <= 6; ++L) bf.featR[L] = (L >= ll && L < 5) ? pl.take((size_t)B * h[L] * w[L] * 128) : nullptr;   // one per level: filled on the side stream
     bf.misc4 = pl.take(px * 4);
     bf.d1 = pl.take(px * 56); bf.dist = pl.take(px * 56);
     bf.partial = pl.take((size_t)B * flow_mean_partials(0) * 2);
@@ -465,8 +482,17 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     RUN(conv(nc[7], {{bf.sa, 96, 96}}, bf.feat[4], 96, 96, nullptr, 0, 1, N2, h[4], w[4], 1, 1, 1, st));
     RUN(conv(nc[8], {{bf.feat[4], 96, 96}}, bf.feat[5], 128, 128, nullptr, 0, 1, N2, h[4], w[4], 2, 1, 1, st));
     RUN(conv(nc[9], {{bf.feat[5], 128, 128}}, bf.feat[6], 192, 192, nullptr, 0, 1, N2, h[5], w[5], 2, 1, 1, st));
-    for (int L = net->lowest; L <= 2; ++L)       // NetC_ext (:353-355)
-        RUN(conv(net->ext[L], {{bf.feat[L], 32, 32}}, bf.ext[L], 64, 64, nullptr, 0, 1, N2, h[L], w[L], 1, 0, 0, st));
+    // Flow-independent 1x1 convs on the side stream, finest level last so the coarse levels get theirs first:
+    // NetC_ext (:353-355) for levels <= 2 and Regularization.moduleFeat (:227-232, applied at :280) for levels < 5.
+    PIV_CHECK_HIP(hipEventRecord(net->ev_fork, st));
+    PIV_CHECK_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
+    for (int L = 6; L >= net->lowest; --L) {
+        if (L < 5)
+            RUN(conv(net->lv[L].feat, {{bf.feat[L], C_FEAT[L], C_FEAT[L]}}, bf.featR[L], 128, 128, nullptr, 0, 1, B, h[L], w[L], 1, 0, 0, net->side));
+        if (L <= 2)
+            RUN(conv(net->ext[L], {{bf.feat[L], 32, 32}}, bf.ext[L], 64, 64, nullptr, 0, 1, N2, h[L], w[L], 1, 0, 0, net->side));
+        PIV_CHECK_HIP(hipEventRecord(net->ev_join[L], net->side));
+    }
 
     float *prev = nullptr, *cur = bf.flowA;
     size_t lvoff = 0;
@@ -480,6 +506,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         const float *im1 = bf.img[L], *im2 = bf.img[L] + half * 4;
         const float sc = net->scale[L];
         const int s = L >= 4 ? 1 : 2;
+        PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0));     // this level's side-stream convs are done
         // ---- Matching (:165-187)
         const float *fup = nullptr;
         if (prev) {
@@ -543,13 +570,8 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         // ---- Regularization (:274-303); note it takes the RAW NetC feature (:361)
         RUN(launch_flow_mean(bf.flowS, bf.partial, bf.mean, B, hh * ww, st));
         RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, sc, bf.misc4, B, hh, ww, st));
-        const float *fr = f1raw;
-        int cfr = cf;
-        if (L < 5) {
-            RUN(conv(lw.feat, {{f1raw, cf, cf}}, bf.featR, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 0, 0, st));
-            fr = bf.featR;
-            cfr = 128;
-        }
+        const float *fr = L < 5 ? bf.featR[L] : f1raw;
+        const int cfr = L < 5 ? 128 : cf;
         RUN(conv(lw.R[0], {{fr, cfr, cfr}, {bf.misc4, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.R[1], {{bf.t128a, 128, 128}}, bf.t128b, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
         RUN(conv(lw.R[2], {{bf.t128b, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));

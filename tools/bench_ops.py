@@ -41,6 +41,7 @@ def bench_warp_corr(args):
     variants = [int(v) for v in args.variants.split(",")]
     for L in [int(x) for x in args.levels.split(",")]:
         C, n, s = LEVELS[L]
+        n = n * args.size // 1024
         f1 = torch.randn(B, n, n, C, device=dev)
         f2 = torch.randn(B, n, n, C, device=dev)
         fl = torch.zeros(B, n, n, 4, device=dev)
@@ -146,6 +147,7 @@ if __name__ == "__main__":
     ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv"])
     ap.add_argument("--filter", default="")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
     ap.add_argument("--variants", default="1,2,0")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
     a = ap.parse_args()
