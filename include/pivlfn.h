@@ -46,6 +46,12 @@ int         pivlfn_tune(int knob, int value);
 int pivlfn_corr_fwd(const float *first, const float *second, float *out,
                     int B, int C, int H, int W, int stride, void *stream);
 
+/* ---- backward of the custom op: replaces _FunctionCorrelation.backward, src/correlation.py:348-405 (+ kernels :106-234).
+ * grad_out: NCHW [B,49,ceil(H/stride),ceil(W/stride)]; grad_first / grad_second: NCHW [B,C,H,W], every element written
+ * (exact zeros off the stride grid); either may be NULL (needs_input_grad false, :353-356). */
+int pivlfn_corr_bwd(const float *first, const float *second, const float *grad_out, float *grad_first, float *grad_second,
+                    int B, int C, int H, int W, int stride, void *stream);
+
 /* ---- replaces backwarp(), src/models.py:20-35.  in: NCHW [B,C,H,W]; flow: NCHW [B,2,H,W] (pixels);
  * out[b,c,y,x] = bilinear(in[b,c], x + flow[b,0,y,x], y + flow[b,1,y,x]), zeros outside. */
 int pivlfn_backwarp(const float *in, const float *flow, float *out,

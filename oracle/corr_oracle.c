@@ -12,6 +12,11 @@
  *   corr_forward       <- _FunctionCorrelation.forward     /root/reference/src/correlation.py:287-344
  *   backwarp_forward   <- backwarp()                       /root/reference/src/models.py:20-35
  *                         (grid_sample bilinear / zeros / align_corners=True, restated in pixel units)
+ *   corr_grad_first    <- kernel_Correlation_updateGradFirst  /root/reference/src/correlation.py:106-166
+ *   corr_grad_second   <- kernel_Correlation_updateGradSecond /root/reference/src/correlation.py:168-234
+ *   corr_backward      <- _FunctionCorrelation.backward       /root/reference/src/correlation.py:348-405
+ *                         (the backward cannot be executed from the reference here -- it exists only as CuPy CUDA text --
+ *                          so its pin is: this loop-for-loop restatement == torch autograd through the pinned forward)
  * nvcc contracts `sum += a*b` into an FMA by default, hence fmaf below.
  *
  * Parity pin: checked against the shimmed import of the reference's own src/models.py in this
@@ -112,5 +117,103 @@ int backwarp_forward(const float *in, const float *flow, float *out, int B, int 
                     out[((size_t)(b * C + c) * H + y) * W + x] = acc;
                 }
             }
+    return 0;
+}
+
+
+/* ---- backward ------------------------------------------------------------------------ */
+#define ROUND_OFF 50000
+
+/* one "thread" per (c, x, y) of gradFirst, sample b; rbot1 = padded NHWC copy of `second`. */
+static void corr_grad_first(int b, const float *rbot1, const float *gout, float *gfirst,
+                            int C, int H, int W, int Ho, int Wo, int s)
+{
+    const int PH = H + 6 * s, PW = W + 6 * s;
+    const int total = C * H * W;
+    for (int idx = 0; idx < total; ++idx) {
+        const int n = idx % C;
+        const int l = (idx / C) % W + 3 * s;
+        const int m = (idx / C / W) % H + 3 * s;
+        const int round_off = ROUND_OFF, round_off_s1 = s * round_off;
+        int xmin = (l - 3 * s + round_off_s1 - 1) / s + 1 - round_off;
+        int ymin = (m - 3 * s + round_off_s1 - 1) / s + 1 - round_off;
+        int xmax = (l - 3 * s + round_off_s1) / s - round_off;
+        int ymax = (m - 3 * s + round_off_s1) / s - round_off;
+        float sum = 0.f;
+        if (xmax >= 0 && ymax >= 0 && xmin <= Wo - 1 && ymin <= Ho - 1) {
+            xmin = xmin > 0 ? xmin : 0;
+            xmax = xmax < Wo - 1 ? xmax : Wo - 1;
+            ymin = ymin > 0 ? ymin : 0;
+            ymax = ymax < Ho - 1 ? ymax : Ho - 1;
+            for (int p = -3; p <= 3; ++p)
+                for (int o = -3; o <= 3; ++o) {
+                    const int s2o = s * o, s2p = s * p;
+                    const float bot1tmp = rbot1[(((size_t)b * PH + (m + s2p)) * PW + (l + s2o)) * C + n];
+                    const int op = (p + 3) * 7 + (o + 3);
+                    for (int y = ymin; y <= ymax; ++y)
+                        for (int x = xmin; x <= xmax; ++x)
+                            sum = fmaf(gout[(((size_t)b * 49 + op) * Ho + y) * Wo + x], bot1tmp, sum);
+                }
+        }
+        gfirst[(((size_t)b * C + n) * H + (m - 3 * s)) * W + (l - 3 * s)] = sum / (float)C;
+    }
+}
+
+/* one "thread" per (c, x, y) of gradSecond, sample b; rbot0 = padded NHWC copy of `first`. */
+static void corr_grad_second(int b, const float *rbot0, const float *gout, float *gsecond,
+                             int C, int H, int W, int Ho, int Wo, int s)
+{
+    const int PH = H + 6 * s, PW = W + 6 * s;
+    const int total = C * H * W;
+    for (int idx = 0; idx < total; ++idx) {
+        const int n = idx % C;
+        const int l = (idx / C) % W + 3 * s;
+        const int m = (idx / C / W) % H + 3 * s;
+        const int round_off = ROUND_OFF, round_off_s1 = s * round_off;
+        float sum = 0.f;
+        for (int p = -3; p <= 3; ++p)
+            for (int o = -3; o <= 3; ++o) {
+                const int s2o = s * o, s2p = s * p;
+                int xmin = (l - 3 * s - s2o + round_off_s1 - 1) / s + 1 - round_off;
+                int ymin = (m - 3 * s - s2p + round_off_s1 - 1) / s + 1 - round_off;
+                int xmax = (l - 3 * s - s2o + round_off_s1) / s - round_off;
+                int ymax = (m - 3 * s - s2p + round_off_s1) / s - round_off;
+                if (xmax >= 0 && ymax >= 0 && xmin <= Wo - 1 && ymin <= Ho - 1) {
+                    xmin = xmin > 0 ? xmin : 0;
+                    xmax = xmax < Wo - 1 ? xmax : Wo - 1;
+                    ymin = ymin > 0 ? ymin : 0;
+                    ymax = ymax < Ho - 1 ? ymax : Ho - 1;
+                    const float bot0tmp = rbot0[(((size_t)b * PH + (m - s2p)) * PW + (l - s2o)) * C + n];
+                    const int op = (p + 3) * 7 + (o + 3);
+                    for (int y = ymin; y <= ymax; ++y)
+                        for (int x = xmin; x <= xmax; ++x)
+                            sum = fmaf(gout[(((size_t)b * 49 + op) * Ho + y) * Wo + x], bot0tmp, sum);
+                }
+            }
+        gsecond[(((size_t)b * C + n) * H + (m - 3 * s)) * W + (l - 3 * s)] = sum / (float)C;
+    }
+}
+
+/* gfirst / gsecond may be NULL (needs_input_grad false). */
+int corr_backward(const float *first, const float *second, const float *gout, float *gfirst, float *gsecond,
+                  int B, int C, int H, int W, int s)
+{
+    const int PH = H + 6 * s, PW = W + 6 * s;
+    const int Ho = (H + s - 1) / s, Wo = (W + s - 1) / s;
+    float *rbot0 = (float *)calloc((size_t)B * PH * PW * C, sizeof(float));
+    float *rbot1 = (float *)calloc((size_t)B * PH * PW * C, sizeof(float));
+    if (!rbot0 || !rbot1) {
+        free(rbot0);
+        free(rbot1);
+        return 1;
+    }
+    corr_rearrange(first, rbot0, B, C, H, W, s);
+    corr_rearrange(second, rbot1, B, C, H, W, s);
+    for (int b = 0; b < B; ++b) {
+        if (gfirst) corr_grad_first(b, rbot1, gout, gfirst, C, H, W, Ho, Wo, s);
+        if (gsecond) corr_grad_second(b, rbot0, gout, gsecond, C, H, W, Ho, Wo, s);
+    }
+    free(rbot0);
+    free(rbot1);
     return 0;
 }

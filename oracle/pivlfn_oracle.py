@@ -55,6 +55,7 @@ def _lib():
         fp = ctypes.POINTER(ctypes.c_float)
         _LIB.corr_forward.argtypes = [fp, fp, fp] + [ctypes.c_int] * 5
         _LIB.backwarp_forward.argtypes = [fp, fp, fp] + [ctypes.c_int] * 4
+        _LIB.corr_backward.argtypes = [fp, fp, fp, fp, fp] + [ctypes.c_int] * 5
     return _LIB
 
 
@@ -71,6 +72,28 @@ def correlation_c(first: np.ndarray, second: np.ndarray, stride: int) -> np.ndar
     if rc != 0:
         raise RuntimeError(f"corr_forward failed rc={rc}")
     return out
+
+
+def correlation_backward_c(first: np.ndarray, second: np.ndarray, grad_out: np.ndarray, stride: int):
+    """(gradFirst, gradSecond) of the reference's backward kernels (src/correlation.py:106-234, 348-405), restated in C."""
+    f1 = np.ascontiguousarray(first, dtype=np.float32)
+    f2 = np.ascontiguousarray(second, dtype=np.float32)
+    go = np.ascontiguousarray(grad_out, dtype=np.float32)
+    B, C, H, W = f1.shape
+    assert go.shape == (B, 49, -(-H // stride), -(-W // stride))
+    g1, g2 = np.empty_like(f1), np.empty_like(f2)
+    rc = _lib().corr_backward(_fp(f1), _fp(f2), _fp(go), _fp(g1), _fp(g2), B, C, H, W, stride)
+    if rc:
+        raise MemoryError("corr_backward")
+    return g1, g2
+
+
+def correlation_backward_autograd(first: torch.Tensor, second: torch.Tensor, grad_out: torch.Tensor, stride: int):
+    """The same gradients by torch autograd through the (pinned) forward restatement `correlation_torch`."""
+    f1 = first.detach().clone().requires_grad_(True)
+    f2 = second.detach().clone().requires_grad_(True)
+    correlation_torch(f1, f2, stride).backward(grad_out)
+    return f1.grad, f2.grad
 
 
 def backwarp_c(inp: np.ndarray, flow: np.ndarray) -> np.ndarray:

@@ -53,6 +53,12 @@ int pivlfn_corr_fwd(const float *first, const float *second, float *out, int B, 
     return launch_warp_corr(first, second, nullptr, 0.f, out, B, C, H, W, stride, 0, false, (hipStream_t)stream);
 }
 
+int pivlfn_corr_bwd(const float *first, const float *second, const float *grad_out, float *grad_first, float *grad_second,
+                    int B, int C, int H, int W, int stride, void *stream)
+{
+    return launch_corr_bwd(first, second, grad_out, grad_first, grad_second, B, C, H, W, stride, (hipStream_t)stream);
+}
+
 int pivlfn_backwarp(const float *in, const float *flow, float *out, int B, int C, int H, int W, void *stream)
 {
     return launch_backwarp_nchw(in, flow, out, B, C, H, W, (hipStream_t)stream);

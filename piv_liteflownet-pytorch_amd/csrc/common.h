@@ -104,6 +104,8 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
                      int B, int C, int H, int W, int stride, int leaky, bool nhwc, hipStream_t st);
 void warp_corr_time_next(hipEvent_t start, hipEvent_t stop);   // attach start/stop events to the next channels-last launch
 int launch_backwarp_nchw(const float *in, const float *flow, float *out, int B, int C, int H, int W, hipStream_t st);
+int launch_corr_bwd(const float *first, const float *second, const float *gout, float *gfirst, float *gsecond,
+                    int B, int C, int H, int W, int s, hipStream_t st);
 
 // ---- small ops (ops.hip); NHWC unless noted ----------------------------------------------------------
 int launch_prep_images(const float *img1, const float *img2, float *out, int B, int H, int W,

@@ -484,15 +484,20 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     RUN(conv(nc[9], {{bf.feat[5], 128, 128}}, bf.feat[6], 192, 192, nullptr, 0, 1, N2, h[5], w[5], 2, 1, 1, st));
     // Flow-independent 1x1 convs on the side stream, finest level last so the coarse levels get theirs first:
     // NetC_ext (:353-355) for levels <= 2 and Regularization.moduleFeat (:227-232, applied at :280) for levels < 5.
-    PIV_CHECK_HIP(hipEventRecord(net->ev_fork, st));
-    PIV_CHECK_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
-    for (int L = 6; L >= net->lowest; --L) {
+    // (Holding level 1's share back until the level-3 warp+correlation has been issued was measured: that launch drops from
+    // 14.6 to 13.4 us -- the 1 GB the side stream writes no longer evicts the level-3 features from the Infinity Cache -- but
+    // the step grows by 0.2 ms because the HBM-bound 1x1 convs then compete with the MFMA-bound stacks.  Not kept.)
+    auto side_level = [&](int L) -> int {
         if (L < 5)
             RUN(conv(net->lv[L].feat, {{bf.feat[L], C_FEAT[L], C_FEAT[L]}}, bf.featR[L], 128, 128, nullptr, 0, 1, B, h[L], w[L], 1, 0, 0, net->side));
         if (L <= 2)
             RUN(conv(net->ext[L], {{bf.feat[L], 32, 32}}, bf.ext[L], 64, 64, nullptr, 0, 1, N2, h[L], w[L], 1, 0, 0, net->side));
         PIV_CHECK_HIP(hipEventRecord(net->ev_join[L], net->side));
-    }
+        return PIVLFN_OK;
+    };
+    PIV_CHECK_HIP(hipEventRecord(net->ev_fork, st));
+    PIV_CHECK_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
+    for (int L = 4; L >= net->lowest; --L) RUN(side_level(L));
 
     float *prev = nullptr, *cur = bf.flowA;
     size_t lvoff = 0;
@@ -506,7 +511,10 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         const float *im1 = bf.img[L], *im2 = bf.img[L] + half * 4;
         const float sc = net->scale[L];
         const int s = L >= 4 ? 1 : 2;
-        PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0));     // this level's side-stream convs are done
+        // Join the side stream only where its results are first read: NetC_ext feeds Matching at levels <= 2, moduleFeat feeds
+        // Regularization at levels 3 and 4.  (A cross-queue wait costs a barrier packet and a cold start for the next
+        // kernel: in front of the level-3 warp+correlation it cost that launch 2 us.)
+        if (L <= 2) PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0));
         // ---- Matching (:165-187)
         const float *fup = nullptr;
         if (prev) {
@@ -570,6 +578,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         // ---- Regularization (:274-303); note it takes the RAW NetC feature (:361)
         RUN(launch_flow_mean(bf.flowS, bf.partial, bf.mean, B, hh * ww, st));
         RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, sc, bf.misc4, B, hh, ww, st));
+        if (L == 3 || L == 4) PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0));
         const float *fr = L < 5 ? bf.featR[L] : f1raw;
         const int cfr = L < 5 ? 128 : cf;
         RUN(conv(lw.R[0], {{fr, cfr, cfr}, {bf.misc4, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));

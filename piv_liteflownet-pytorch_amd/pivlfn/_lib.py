@@ -21,6 +21,7 @@ SIGNATURES = {
     "pivlfn_abi_version": (ctypes.c_int, []),
     "pivlfn_tune": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "pivlfn_corr_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "pivlfn_corr_bwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "pivlfn_backwarp": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "pivlfn_warp_corr_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
     "pivlfn_warp_corr_nhwc": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]),

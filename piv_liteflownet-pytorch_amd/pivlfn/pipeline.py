@@ -1,0 +1,179 @@
+"""Streaming input/output pipeline around `estimate` for run.py (reference loop: run.py:137-168).
+
+The reference reads, converts, uploads, infers, downloads and writes one pair at a time on one thread
+(`for images, fname in tqdm(dataset)`: run.py:155-166).  Here the three stages overlap:
+
+  loader thread : decode each frame ONCE (sequence mode reuses frame i+1 of pair i as frame i of pair i+1), as uint8 HWC,
+                  group equal-sized pairs into batches, stage them in pinned host memory          (PairLoader)
+  main thread   : H2D of the uint8 batch on a copy stream, uint8 -> fp32 NCHW / 255 on the device (the arithmetic of
+                  torchvision's ToTensor that the reference uses, src/datasets.py:452-453), `estimate`
+  D2H + writer  : flow -> pinned buffer on the copy stream, an event per batch; the writer threads wait on the event and
+                  write the .flo files while the next batch is being computed                      (drain / FloWriter)
+
+Nothing here touches the numerical path: `estimate(net, a, b)` receives exactly the tensors the reference would build.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Callable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def read_image_u8(path: str) -> np.ndarray:
+    """PIL -> RGB -> uint8 [H,W,3] (read_gen of the reference, src/utils_data.py:46-56, before ToTensor)."""
+    import PIL.Image
+    return np.array(PIL.Image.open(path).convert("RGB"), dtype=np.uint8)
+
+
+_LUT = {}
+
+
+def u8_to_input(x: torch.Tensor) -> torch.Tensor:
+    """uint8 [n,H,W,3] -> float32 [n,3,H,W] in [0,1], bit-identical to ToTensor's `byte -> float -> div(255)` on the CPU.
+    On the GPU torch evaluates `t / 255` as `t * (1/255)`, which differs from the division in the last bit for some of the
+    256 values, so the 256 correctly-divided results are tabulated once on the host and gathered on the device."""
+    key = str(x.device)
+    if key not in _LUT:
+        _LUT[key] = (torch.arange(256, dtype=torch.float32) / 255.0).to(x.device)
+    n, H, W, C = x.shape
+    flat = _LUT[key].index_select(0, x.reshape(-1).to(torch.int32))
+    return flat.view(n, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+class PairLoader:
+    """Iterates `(names, img1_u8, img2_u8)` batches ([n,H,W,3] uint8 torch tensors, pinned when `pin`), in dataset order,
+    over pairs [lo, hi) of a `Run`-like dataset (anything with `.image_list[i] = [path1, path2]` and `.name_list[i]`).
+    A batch never mixes image sizes.  Decoding runs on a background thread, `depth` batches ahead."""
+
+    def __init__(self, dataset, lo: int, hi: int, batch: int, depth: int = 2, pin: bool = False,
+                 reader: Callable[[str], np.ndarray] = read_image_u8):
+        if batch < 1 or depth < 1:
+            raise ValueError("PairLoader: batch and depth must be >= 1")
+        self.ds, self.lo, self.hi, self.batch, self.pin, self.reader = dataset, lo, hi, batch, pin, reader
+        self.decoded = 0                                   # frames actually decoded (tests: sequence mode decodes n+1, not 2n)
+        self._q: "queue.Queue" = queue.Queue(maxsize=depth)
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._produce, daemon=True)
+        self._thread.start()
+
+    # ---- producer ------------------------------------------------------------------------------------------------
+    def _frame(self, path: str, cache: dict) -> np.ndarray:
+        if path in cache:
+            return cache[path]
+        a = self.reader(path)
+        self.decoded += 1
+        return a
+
+    def _emit(self, names: List[str], f1: List[np.ndarray], f2: List[np.ndarray]) -> bool:
+        def stack(frames):
+            t = torch.from_numpy(np.stack(frames))
+            return t.pin_memory() if self.pin else t
+        item = (names, stack(f1), stack(f2))
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _produce(self) -> None:
+        try:
+            names: List[str] = []
+            f1: List[np.ndarray] = []
+            f2: List[np.ndarray] = []
+            cache: dict = {}
+            for i in range(self.lo, self.hi):
+                p1, p2 = self.ds.image_list[i]
+                a = self._frame(p1, cache)
+                b = self._frame(p2, cache)
+                cache = {p2: b}                            # the only frame a following pair can share (src/datasets.py:456-463)
+                if a.shape != b.shape:
+                    raise ValueError(f"pair '{self.ds.name_list[i]}': image sizes differ {a.shape} vs {b.shape}")
+                if names and (len(names) == self.batch or a.shape != f1[0].shape):
+                    if not self._emit(names, f1, f2):
+                        return
+                    names, f1, f2 = [], [], []
+                names.append(self.ds.name_list[i])
+                f1.append(a)
+                f2.append(b)
+            if names and not self._emit(names, f1, f2):
+                return
+            self._q.put(None)
+        except BaseException as e:                         # noqa: BLE001  -- re-raised on the consumer side
+            self._q.put(e)
+
+    # ---- consumer ------------------------------------------------------------------------------------------------
+    def __iter__(self) -> Iterator[Tuple[List[str], torch.Tensor, torch.Tensor]]:
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self) -> None:
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5.0)
+
+
+def stream_pairs(net, loader: PairLoader, device: torch.device, sink: Callable[[np.ndarray, str], None],
+                 estimate_fn: Optional[Callable] = None, in_flight: int = 2) -> int:
+    """Drive `estimate` over a PairLoader.  `sink(flow_hw2, name)` is called once per pair, in order; the numpy view it gets
+    owns a reference to its (pinned) batch buffer, so an asynchronous writer may keep it.  On a GPU the uploads and
+    downloads run on a copy stream and overlap with compute; on the CPU (tests of the host logic, with a stand-in
+    `estimate_fn`) the same code runs synchronously."""
+    if estimate_fn is None:
+        from .inference import estimate as estimate_fn      # noqa: N813
+    on_gpu = device.type == "cuda"
+    copy = torch.cuda.Stream(device) if on_gpu else None
+    pending: List[Tuple[Optional[torch.cuda.Event], torch.Tensor, Sequence[str]]] = []
+    done = 0
+
+    def drain(keep: int) -> None:
+        nonlocal done
+        while len(pending) > keep:
+            ev, host, names = pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            arr = host.numpy()
+            for k, name in enumerate(names):
+                sink(arr[k], name)
+            done += len(names)
+
+    for names, a8, b8 in loader:
+        if on_gpu:
+            main = torch.cuda.current_stream(device)
+            with torch.cuda.stream(copy):
+                a_dev = a8.to(device, non_blocking=True)
+                b_dev = b8.to(device, non_blocking=True)
+            main.wait_stream(copy)
+            a_dev.record_stream(main)
+            b_dev.record_stream(main)
+        else:
+            a_dev, b_dev = a8, b8
+        flow = estimate_fn(net, u8_to_input(a_dev), u8_to_input(b_dev), tensor=True)      # [n,2,H,W]
+        out = flow.permute(0, 2, 3, 1).contiguous()                                      # [n,H,W,2], the .flo layout
+        if on_gpu:
+            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            copy.wait_stream(main)
+            with torch.cuda.stream(copy):
+                host.copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy)
+            out.record_stream(copy)
+            pending.append((ev, host, names))
+        else:
+            pending.append((None, out, names))
+        drain(in_flight - 1)
+    drain(0)
+    return done

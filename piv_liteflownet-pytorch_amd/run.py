@@ -6,8 +6,9 @@
 Same flags and output layout (OUT/<netname>/<input-basename>[-start_num]/flow[/left|right]/<name>_out.flo, args.txt).
 Differences: `--weights` names the state dict (the reference hard-codes models/pretrain_torch/*.paramOnly, which are not
 shipped); without it, or with `--synthetic_weights`, the seeded generator of pivlfn.synth is used.  `--no_cuda` is an
-error (there is no CPU path).  Pairs of equal size are batched (`--batch`), `.flo` files are written by a background
-writer, and under torch.distributed.run the pairs are sharded over the ranks (pivlfn.dist.shard_bounds).
+error (there is no CPU path).  Pairs of equal size are batched (`--batch`); frames are decoded once on a prefetch thread,
+staged in pinned memory and converted uint8 -> fp32 on the device; flows come back on a copy stream and `.flo` files are
+written by a background writer while the next batch computes (pivlfn.pipeline), and under torch.distributed.run the pairs are sharded over the ranks (pivlfn.dist.shard_bounds).
 """
 import argparse
 import os
@@ -22,6 +23,7 @@ from pivlfn import Network, estimate                     # noqa: E402
 from pivlfn.datasets import Run                          # noqa: E402
 from pivlfn.dist import shard_bounds                     # noqa: E402
 from pivlfn.flo import FloWriter, flowname_modifier      # noqa: E402
+from pivlfn.pipeline import PairLoader, stream_pairs     # noqa: E402
 from pivlfn import synth                                 # noqa: E402
 
 parser = argparse.ArgumentParser(description="Inferencing script for LiteFlowNet (MI355X-native path)")
@@ -58,22 +60,14 @@ def main_dl(net, inputdir, savedir, is_pair, start_id, num_images, device, batch
     ds = Run(root=inputdir, is_pair=is_pair, n_images=num_images, start_at=start_id)
     lo, hi = shard_bounds(len(ds), rank, world)
     print(f"Processing {hi - lo} of {len(ds)} pairs of images (rank {rank}/{world})...")
-    with FloWriter() as writer:
-        i = lo
-        while i < hi:
-            items = [ds[i]]
-            shape = items[0][0][0].shape
-            while len(items) < batch and i + len(items) < hi:
-                nxt = ds[i + len(items)]
-                if nxt[0][0].shape != shape:
-                    break
-                items.append(nxt)
-            a = torch.stack([it[0][0] for it in items]).to(device, non_blocking=True)
-            b = torch.stack([it[0][1] for it in items]).to(device, non_blocking=True)
-            flow = estimate(net, a, b, tensor=True).permute(0, 2, 3, 1).contiguous().cpu().numpy()
-            for k, it in enumerate(items):
-                writer.submit(flow[k], flowname_modifier(it[1], savedir, pair=False))
-            i += len(items)
+    loader = PairLoader(ds, lo, hi, batch, depth=2, pin=device.type == "cuda")
+    try:
+        with FloWriter() as writer:
+            n = stream_pairs(net, loader, device,
+                             lambda flow, name: writer.submit(flow, flowname_modifier(name, savedir, pair=False)))
+    finally:
+        loader.close()
+    assert n == hi - lo
     return hi - lo
 
 

@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def gold():
-    return {k: np.load(os.path.join(GOLD, k + ".npz")) for k in ("corr_cases", "backwarp_cases", "e2e_cases")}
+    return {k: np.load(os.path.join(GOLD, k + ".npz")) for k in ("corr_cases", "backwarp_cases", "e2e_cases", "corr_bwd_cases")}
 
 
 @pytest.fixture(scope="session")

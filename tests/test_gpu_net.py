@@ -137,24 +137,25 @@ def test_full_size_1024_properties(nets, dev):
 
 
 def test_run_py_end_to_end(tmp_path, dev):
-    """run.py counterpart: a 3-frame sequence and a pair folder -> .flo files equal to estimate() on the same pairs."""
+    """run.py counterpart: a 6-frame sequence (5 pairs, 3 batches through the copy-stream pipeline) -> .flo files equal to
+    estimate() on the same pairs."""
     import PIL.Image
     import run as runpy
     from pivlfn.flo import read_flow
     seq = tmp_path / "seq"
     seq.mkdir()
     frames = []
-    for k in range(3):
+    for k in range(6):
         a, _, _ = synth.particle_pair(64, 96, 400 + k)
         frames.append(a)
         PIL.Image.fromarray(a).save(str(seq / f"frame_{k:04d}.png"))
     out = tmp_path / "out"
     n = runpy.main(["--model", "piv", "-i", str(seq), "-o", str(out), "--batch", "2"])
-    assert n == 2
+    assert n == 5
     flodir = out / "piv-synthetic" / "seq" / "flow"
     assert (out / "piv-synthetic" / "seq" / "args.txt").exists()
     net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
-    for k in range(2):
+    for k in range(5):
         got = read_flow(str(flodir / f"frame_{k:04d}_out.flo"))
         i1 = torch.from_numpy(synth.to_input(frames[k]))[None].to(dev)
         i2 = torch.from_numpy(synth.to_input(frames[k + 1]))[None].to(dev)

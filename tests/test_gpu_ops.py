@@ -140,3 +140,66 @@ def test_resize_bilinear_matches_torch(dev):
         want[:, 0::2] *= 0.5
         want[:, 1::2] *= 3.0
         assert rel(out.cpu().numpy(), want.numpy()) < 1e-5
+
+
+# ---- correlation backward (src/correlation.py:106-234, 348-405) -------------------------------------------
+def _corr_grads(f1, f2, go, s, dev, need=(True, True)):
+    a = torch.from_numpy(f1).to(dev).requires_grad_(need[0])
+    b = torch.from_numpy(f2).to(dev).requires_grad_(need[1])
+    out = pivlfn.FunctionCorrelation(a, b, s)
+    out.backward(torch.from_numpy(go).to(dev))
+    return a.grad, b.grad
+
+
+def test_correlation_backward_golden(gold, dev):
+    g = gold["corr_bwd_cases"]
+    n = 0
+    while f"f1_{n}" in g:
+        f1, f2, go, s = g[f"f1_{n}"], g[f"f2_{n}"], g[f"go_{n}"], int(g[f"stride_{n}"])
+        g1, g2 = _corr_grads(f1, f2, go, s, dev)
+        assert g1.shape == f1.shape and g2.shape == f2.shape and g1.is_contiguous()
+        assert rel(g1.cpu().numpy(), g[f"g1_{n}"]) < OP_TOL, n
+        assert rel(g2.cpu().numpy(), g[f"g2_{n}"]) < OP_TOL, n
+        if s > 1:                                   # the reference writes exact zeros off the stride grid
+            off = np.ones(f1.shape[2:], bool)
+            off[::s, ::s] = False
+            assert not g1.cpu().numpy()[:, :, off].any() and not g2.cpu().numpy()[:, :, off].any()
+        n += 1
+    assert n >= 8
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 32, 48, 1), (2, 96, 17, 23, 1), (1, 64, 64, 64, 2), (3, 20, 31, 45, 2),
+                                   (1, 7, 1, 1, 1), (2, 33, 5, 40, 2), (1, 16, 50, 50, 3)])
+def test_correlation_backward_vs_oracle(shape, dev):
+    B, C, H, W, s = shape
+    g = np.random.default_rng(hash(shape) % 2 ** 31)
+    f1 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    f2 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    go = g.standard_normal((B, 49, -(-H // s), -(-W // s))).astype(np.float32)
+    w1, w2 = orc.correlation_backward_c(f1, f2, go, s)
+    g1, g2 = _corr_grads(f1, f2, go, s, dev)
+    assert rel(g1.cpu().numpy(), w1) < OP_TOL and rel(g2.cpu().numpy(), w2) < OP_TOL
+
+
+def test_correlation_backward_needs_input_grad_and_module(dev):
+    g = np.random.default_rng(5)
+    f1 = g.standard_normal((1, 8, 10, 12)).astype(np.float32)
+    f2 = g.standard_normal((1, 8, 10, 12)).astype(np.float32)
+    go = g.standard_normal((1, 49, 10, 12)).astype(np.float32)
+    full1, full2 = _corr_grads(f1, f2, go, 1, dev)
+    only1, none2 = _corr_grads(f1, f2, go, 1, dev, need=(True, False))
+    none1, only2 = _corr_grads(f1, f2, go, 1, dev, need=(False, True))
+    assert none1 is None and none2 is None
+    assert torch.equal(only1, full1) and torch.equal(only2, full2)
+    a = torch.from_numpy(f1).to(dev).requires_grad_(True)
+    b = torch.from_numpy(f2).to(dev).requires_grad_(True)
+    pivlfn.ModuleCorrelation()(a, b, 1).backward(torch.from_numpy(go).to(dev).transpose(2, 3).contiguous().transpose(2, 3))
+    assert torch.equal(a.grad, full1) and torch.equal(b.grad, full2)      # a non-contiguous gradient is accepted
+    # the adjoint identity <corr(f1,f2), go> derivative: d/de <corr(f1+e*d, f2), go> = <gradFirst, d>
+    d = torch.from_numpy(g.standard_normal(f1.shape).astype(np.float32)).to(dev)
+    e = 1e-2
+    c_p = pivlfn.FunctionCorrelation((a.detach() + e * d).contiguous(), b.detach(), 1)
+    c_m = pivlfn.FunctionCorrelation((a.detach() - e * d).contiguous(), b.detach(), 1)
+    lhs = float(((c_p - c_m).double() * torch.from_numpy(go).to(dev).double()).sum() / (2 * e))
+    rhs = float((full1.double() * d.double()).sum())
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(rhs))
