@@ -93,6 +93,15 @@ size_t pivlfn_workspace_bytes(const pivlfn_net *net, int B, int H, int W);
 int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels,
                    int B, int H, int W, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Precision of the conv stacks inside pivlfn_forward: PIVLFN_PRECISION_F32 (default: fp32 operands on the fp32 matrix-core
+ * instruction, the mode every fp32 parity statement and the headline benchmark refer to) or PIVLFN_PRECISION_F16 (BASELINE
+ * config #5: operands rounded to fp16 while they are staged, fp32 accumulation, activations still fp32 in HBM; flows agree
+ * with the fp32 mode to an end-point error stated in tests/test_gpu_f16.py).  Everything that is not a convolution
+ * (correlation, warps, flow heads, regularisation tail) is fp32 in both modes. */
+#define PIVLFN_PRECISION_F32 0
+#define PIVLFN_PRECISION_F16 1
+int pivlfn_set_precision(pivlfn_net *net, int precision);
+
 /* Number of floats `levels` must hold for pivlfn_forward. */
 size_t pivlfn_levels_floats(const pivlfn_net *net, int B, int H, int W);
 
@@ -108,6 +117,12 @@ int pivlfn_conv_destroy(pivlfn_conv *conv);
 int pivlfn_conv2d_nhwc(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                        const float *res, int res_stride, int B, int H, int W, int stride, int pad_y, int pad_x,
                        int leaky, void *stream);
+/* The same layer in the optional reduced-precision mode (BASELINE config #5: fp16 multiplicands, fp32 accumulation, on
+ * v_mfma_f32_32x32x16_f16): x is fp32 or fp16 elements (x_is_f16; stride granularity 4 / 8 elements), y is stored as fp32
+ * or fp16 (y_is_f16).  No residual input. */
+int pivlfn_conv2d_nhwc_f16(const pivlfn_conv *conv, const void *x, int x_stride, int x_is_f16, void *y, int y_stride,
+                           int y_is_f16, int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, void *stream);
+
 /* The 32 -> 2 channel k x k flow head (conv_M.6 / conv_S.6) on its dedicated kernel: x [B,H,W,32], res4/out4 [B,H,W,4]. */
 int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W,
                           void *stream);

@@ -95,6 +95,26 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);
+
+// ---- fp16-multiplicand variant (conv_f16.hip): optional reduced-precision mode, K chunks of 16 channels ----------------
+struct ConvSegH {
+    const void *ptr;    // NHWC base (fp32 or fp16 elements), channel offset already applied
+    int cload;          // channels staged from this source: multiple of 4 (fp32) or 8 (fp16); zero-weight lanes allowed
+    int stride;         // elements between consecutive pixels
+    int f16;            // element type of this source: 0 = fp32 (converted while staging), 1 = fp16
+};
+struct ConvParamsH {
+    ConvSegH seg[3];
+    int nseg;
+    const void *wpk;    // fp16 [nchunk][KH*KW][2][cout_pad][8]
+    const float *bias;  // [cout_pad]
+    void *out;          // NHWC fp32 or fp16
+    int out_stride, cout_store, cout_pad, out_f16;
+    int B, H, W, Ho, Wo;
+    int KH, KW, S, padY, padX;
+    int nchunk, lrelu;
+};
+int launch_conv_h(const ConvParamsH &p, hipStream_t st);
 // 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device
 int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                      int k, hipStream_t st);

@@ -15,9 +15,14 @@ static const int C_MATCH[7] = {0, 64, 64, 64, 96, 128, 192};    // NetC_ext: src
 
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 
+void pack_conv_h(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
+                 std::vector<unsigned short> &pk, int *nchunk_out);      // conv_f16.hip
+
 struct ConvW {
     float *wpk = nullptr, *bias = nullptr;
     int cout = 0, cout_pad = 0, KH = 0, KW = 0, nchunk = 0, tail = 0;
+    void *wpk_h = nullptr;         // fp16 packing for conv_f16.hip (K chunks of 16 channels)
+    int nchunk_h = 0;
 };
 
 struct LevelW {
@@ -46,6 +51,7 @@ struct pivlfn_net {
     int nstack = 3;                // hidden conv_M / conv_S layers: 3 = LiteFlowNet (src/models.py:154-163), 5 = LiteFlowNet2 (:487-500)
     int width[5] = {128, 64, 32, 0, 0};
     float mean[6];
+    int precision = 0;             // 0 = fp32 everywhere (default); 1 = fp16 multiplicands in the conv stacks (conv_f16.hip)
     pivlfn::ConvW netc[10];
     pivlfn::ConvW ext[3];          // index by level (1,2)
     pivlfn::LevelW lv[7];
@@ -135,6 +141,17 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
     out->cout = cout; out->cout_pad = cp; out->KH = kh; out->KW = kw; out->nchunk = nchunk; out->tail = tail;
     int rc = upload(net, pk, &out->wpk);
     if (rc) return rc;
+    {   // the fp16 packing of the same layer (optional reduced-precision mode)
+        std::vector<int> cr, cl, co;
+        for (auto &sg : segs) { cr.push_back(sg.creal); cl.push_back(sg.cload); co.push_back(sg.coff); }
+        std::vector<unsigned short> ph;
+        pack_conv_h(w->data, cout, cin, taps, cr.data(), cl.data(), co.data(), (int)segs.size(), ph, &out->nchunk_h);
+        void *d = nullptr;
+        PIV_CHECK_HIP(hipMalloc(&d, ph.size() * sizeof(unsigned short)));
+        net->allocs.push_back(d);
+        PIV_CHECK_HIP(hipMemcpy(d, ph.data(), ph.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        out->wpk_h = d;
+    }
     return upload(net, bias, &out->bias);
 }
 
@@ -431,9 +448,27 @@ size_t net_levels_floats(const pivlfn_net *net, int B, int H, int W)
     return n;
 }
 
+static thread_local int t_precision = 0;      // set by net_forward for the duration of one forward
+
 static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out, int out_stride, int cout_store,
                 const float *res, int res_stride, int lrelu, int B, int H, int W, int S, int padY, int padX, hipStream_t st)
 {
+    const int Ho = (H + 2 * padY - cw.KH) / S + 1, Wo = (W + 2 * padX - cw.KW) / S + 1;
+    // fp16 mode: every residual-free conv whose output grid is at least 64x64 (smaller levels are launch-latency-bound and
+    // stay on the fp32 kernel); activations stay fp32 in HBM, operands are rounded to fp16 while they are staged.
+    if (t_precision == 1 && !res && (long)Ho * Wo >= 64 * 64) {
+        ConvParamsH q;
+        memset(&q, 0, sizeof(q));
+        int i = 0;
+        for (auto &sg : segs) q.seg[i++] = ConvSegH{sg.ptr, sg.cload, sg.stride, 0};
+        q.nseg = i;
+        q.wpk = cw.wpk_h; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
+        q.cout_pad = cw.cout_pad; q.out_f16 = 0;
+        q.B = B; q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
+        q.KH = cw.KH; q.KW = cw.KW; q.S = S; q.padY = padY; q.padX = padX;
+        q.nchunk = cw.nchunk_h; q.lrelu = lrelu;
+        return launch_conv_h(q, st);
+    }
     ConvParams p;
     memset(&p, 0, sizeof(p));
     int i = 0;
@@ -443,10 +478,40 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
     p.cout_pad = cw.cout_pad; p.res = res; p.res_stride = res_stride;
     p.B = B; p.H = H; p.W = W;
     p.KH = cw.KH; p.KW = cw.KW; p.S = S; p.padY = padY; p.padX = padX;
-    p.Ho = (H + 2 * padY - cw.KH) / S + 1;
-    p.Wo = (W + 2 * padX - cw.KW) / S + 1;
+    p.Ho = Ho;
+    p.Wo = Wo;
     p.nchunk = cw.nchunk; p.tail = cw.tail; p.lrelu = lrelu;
     return launch_conv(p, st);
+}
+
+int net_set_precision(pivlfn_net *net, int precision)
+{
+    PIV_REQUIRE(net && (precision == 0 || precision == 1), "set_precision: 0 (fp32) or 1 (fp16 multiplicands) expected");
+    net->precision = precision;
+    return PIVLFN_OK;
+}
+
+// Standalone layer in the fp16 mode (tests, tools): x / y element types chosen per call.
+int conv_forward_h(const pivlfn_conv *c, const void *x, int x_stride, int x_f16, void *y, int y_stride, int y_f16,
+                   int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, hipStream_t st)
+{
+    PIV_REQUIRE(c && x && y, "conv2d_f16: null argument");
+    const int g = x_f16 ? 8 : 4;
+    PIV_REQUIRE(x_stride % g == 0 && x_stride >= rup(c->cin, g), "conv2d_f16: x_stride=%d must be a multiple of %d and >= %d", x_stride, g, rup(c->cin, g));
+    PIV_REQUIRE(y_stride % 4 == 0 && y_stride >= c->cw.cout, "conv2d_f16: y_stride=%d must be a multiple of 4 and >= cout=%d", y_stride, c->cw.cout);
+    PIV_REQUIRE(stride >= 1 && pad_y >= 0 && pad_x >= 0 && H + 2 * pad_y >= c->cw.KH && W + 2 * pad_x >= c->cw.KW, "conv2d_f16: bad geometry");
+    ConvParamsH q;
+    memset(&q, 0, sizeof(q));
+    q.seg[0] = ConvSegH{x, rup(c->cin, g), x_stride, x_f16};
+    q.nseg = 1;
+    q.wpk = c->cw.wpk_h; q.bias = c->cw.bias; q.out = y; q.out_stride = y_stride;
+    q.cout_store = std::min(rup(c->cw.cout, 4), y_stride);
+    q.cout_pad = c->cw.cout_pad; q.out_f16 = y_f16;
+    q.B = B; q.H = H; q.W = W; q.KH = c->cw.KH; q.KW = c->cw.KW; q.S = stride; q.padY = pad_y; q.padX = pad_x;
+    q.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
+    q.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
+    q.nchunk = c->cw.nchunk_h; q.lrelu = leaky;
+    return launch_conv_h(q, st);
 }
 
 int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels, int B, int H, int W,
@@ -456,6 +521,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     PIV_REQUIRE(B > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
                 "forward: H=%d W=%d must be positive multiples of 32 (use estimate() for other sizes)", H, W);
     PIV_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "forward: workspace must be 256-byte aligned");
+    t_precision = net->precision;
     Plan pl; Buffers bf;
     pl.base = reinterpret_cast<char *>(ws);
     plan(net, B, H, W, pl, bf);

@@ -77,6 +77,22 @@ class LiteFlowNet(torch.nn.Module):
         self._handle = None
         self._handle_key = None
         self._ws = None
+        self._precision = "fp32"
+
+    # -- precision of the conv stacks (BASELINE config #5) ------------------------------------------------
+    @property
+    def precision(self) -> str:
+        """'fp32' (default, the mode all fp32 parity statements refer to) or 'fp16' (fp16 multiplicands with fp32
+        accumulation in every convolution whose output grid is at least 64x64; everything else stays fp32)."""
+        return self._precision
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        self._precision = value
+        if self.__dict__.get("_handle") is not None:
+            _lib.check(_lib.load().pivlfn_set_precision(self._handle, 1 if value == "fp16" else 0), "set_precision")
 
     # -- parameter tree --------------------------------------------------------------------------------
     def _fan_in_of_bias(self, name: str) -> int:
@@ -122,6 +138,8 @@ class LiteFlowNet(torch.nn.Module):
             _lib.check(lib.pivlfn_create(arr, len(host), self.starting_scale, self.lowest_level, mean, ctypes.byref(h)),
                        "LiteFlowNet: weight upload")
         self._handle, self._handle_key = h, key
+        if self._precision == "fp16":
+            _lib.check(lib.pivlfn_set_precision(h, 1), "set_precision")
         return h
 
     def _release(self):
