@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
     const int npix = PH * PW;
     _Float16 *patch = hsmem;
     _Float16 *wts = hsmem + npix * HPITCH;
+    float *lbias = reinterpret_cast<float *>(wts + taps * 2 * BN * 8);      // this workgroup's BN biases (see the epilogue)
 
     const int tiles_x = (p.Wo + 31) >> 5;
     const int tiles_y = (p.Ho + TH - 1) / TH;
@@ -55,6 +56,8 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
     const int lane = tid & 63, wave = tid >> 6;
     const int row = lane & 31, hh = lane >> 5;
     const int sub = tid & 1;
+
+    if (tid < BN) lbias[tid] = p.bias[n0 + tid];       // visible after the first barrier of the K loop
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
 #define CH_LOAD(CH)                                                                               \
     do {                                                                                          \
         ld_f16 = sf16;                                                                            \
+        if (p.dbg & 2) break;                                                                     \
         if (sf16) {                                                                               \
             const bool ok_ = c0 + 8 * sub < scl;                                                  \
             _Pragma("unroll") for (int i = 0; i < PM; ++i) {                                      \
@@ -122,7 +126,8 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
     CH_LOAD(0);
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         // registers -> LDS (waits for this chunk's loads), converting fp32 sources to fp16
-        if (ld_f16) {
+        if (p.dbg & 4) {
+        } else if (ld_f16) {
 #pragma unroll
             for (int i = 0; i < PM; ++i)
                 if (poff[i] != -2)
@@ -137,9 +142,11 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
                     *reinterpret_cast<h4 *>(d + 8) = h4{(_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
                 }
         }
+        if (!(p.dbg & 4)) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
-            if (tid + 256 * i < nw) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+            for (int i = 0; i < WM; ++i)
+                if (tid + 256 * i < nw) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+        }
         __syncthreads();
         if (chunk + 1 < p.nchunk) {
             c0 += 16;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
             CH_LOAD(chunk + 1);
         }
         int tap = 0;
-        for (int ky = 0; ky < p.KH; ++ky) {
+        for (int ky = 0; ky < ((p.dbg & 1) ? 0 : p.KH); ++ky) {
             for (int kx = 0; kx < p.KW; ++kx, ++tap) {
                 const int toff = (ky * PW + kx) * HPITCH;
                 h8 a[MT], wq[NT];
@@ -172,6 +179,8 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
 #undef CH_LOAD
 
     // Epilogue: lane&31 = pixel, registers 4g..4g+3 = channels 8g + 4*hh + {0..3} (same D layout as the fp32 kernel).
+    // The bias comes from LDS: with the whole register file in use the 32 per-store global bias loads of the fp32 kernel's
+    // epilogue cannot be batched and serialise, one L2 round trip each (measured: 16 us per tile, a third of the kernel).
     {
         const int ox = x0 + row;
         const bool interior = x0 + 32 <= p.Wo && y0 + TH <= p.Ho && n0 + BN <= p.cout_store;
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
                     const int ch = n0 + n * 32 + 8 * g + 4 * hh;
                     if (!pix_ok || (!interior && ch >= p.cout_store)) continue;
                     f32x4 v = {acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
-                    v += *reinterpret_cast<const f32x4 *>(p.bias + ch);
+                    v += *reinterpret_cast<const f32x4 *>(lbias + (ch - n0));
                     if (p.lrelu) {
                         v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
                     }
@@ -207,7 +216,7 @@ static int launch_h(const ConvParamsH &p, hipStream_t st)
 {
     constexpr int TH = 4 * MT, BN = NT * 32;
     const int PH = (TH - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
-    const size_t lds = ((size_t)PH * PW * HPITCH + (size_t)p.KH * p.KW * 2 * BN * 8) * sizeof(_Float16);
+    const size_t lds = ((size_t)PH * PW * HPITCH + (size_t)p.KH * p.KW * 2 * BN * 8) * sizeof(_Float16) + BN * sizeof(float);
     PIV_REQUIRE(lds <= 160 * 1024, "conv_f16: LDS tile of %zu bytes exceeds 160 KiB (k=%dx%d s=%d)", lds, p.KH, p.KW, p.S);
     PIV_REQUIRE(PH * PW * 2 <= 256 * PM && p.KH * p.KW * 2 * BN <= 256 * WM, "conv_f16: internal staging bound exceeded");
     static bool attr_set = false;
@@ -223,8 +232,10 @@ static int launch_h(const ConvParamsH &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
-int launch_conv_h(const ConvParamsH &p, hipStream_t st)
+int launch_conv_h(const ConvParamsH &p_in, hipStream_t st)
 {
+    ConvParamsH p = p_in;
+    p.dbg = g_knob[3];
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.nchunk >= 1, "conv_f16: bad segment description");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0, "conv_f16: bad output channel counts");
     for (int i = 0; i < p.nseg; ++i)
@@ -237,7 +248,8 @@ int launch_conv_h(const ConvParamsH &p, hipStream_t st)
     const bool big = tiles16 >= 192;         // enough 16-row tiles to give (almost) every CU one
     if (s1_3x3) {
         if (nt == 4) return big ? launch_h<4, 4, 5, 9>(p, st) : launch_h<2, 4, 5, 9>(p, st);
-        if (nt == 2) return big ? launch_h<4, 2, 5, 9>(p, st) : launch_h<2, 2, 5, 9>(p, st);
+        // 64 channels: the 8-row tile fits twice per CU (128->64 at 1024^2: 242 us vs 293 us for the 16-row tile)
+        if (nt == 2) return (big && (g_knob[1] & 64)) ? launch_h<4, 2, 5, 9>(p, st) : launch_h<2, 2, 5, 9>(p, st);
         return big ? launch_h<4, 1, 5, 9>(p, st) : launch_h<2, 1, 5, 9>(p, st);
     }
     // everything else (stride 2, 7x7, separable k x 1 / 1 x k): 8-row tiles, the larger staging class

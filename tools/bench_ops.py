@@ -108,6 +108,7 @@ CONV_SHAPES = [
 def bench_conv(args):
     import ctypes
     lib = _lib.load()
+    lib.pivlfn_tune(3, args.tune3)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     variants = [int(v) for v in args.variants.split(",")]
@@ -126,17 +127,29 @@ def bench_conv(args):
         ys = -(-co // 4) * 4
         flop = 2.0 * B * no * mo * co * ci * kh * kw
         outs = {}
+        xh = None
         for v in variants:
-            y = torch.empty(B, no, mo, ys, device=dev)
+            # variants >= 1000 select the fp16-multiplicand kernel: even = fp32 in / fp32 out, odd = fp16 in / fp16 out;
+            # (v - 1000) >> 1 goes to the tuning knob (pivlfn_tune(1, .)): 1000/1001 shipped policy, 1128/1129 = knob 64
+            f16io = v >= 1000 and (v & 1) == 1
+            y = torch.empty(B, no, mo, ys, device=dev, dtype=torch.float16 if f16io else torch.float32)
             outs[v] = y
+            if f16io and xh is None and ci % 8 == 0:
+                xh = x.half()
 
-            def fn(v=v, y=y):
-                lib.pivlfn_tune(1, v)
-                _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+            def fn(v=v, y=y, f16io=f16io):
+                lib.pivlfn_tune(1, (v - 1000) >> 1 if v >= 1000 else v)
+                if v >= 1000:
+                    if f16io and ci % 8 == 0:
+                        _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, xh.data_ptr(), ci, 1, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                    else:
+                        _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, x.data_ptr(), ci, 0, y.data_ptr(), ys, 1 if f16io else 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                else:
+                    _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
             tmin, tmed = time_it(fn, n=10 if flop > 2e10 else 30, rounds=4)
             print(f"{name:28s} B={B} variant {v}: min {tmin:9.1f} us  med {tmed:9.1f} us  {flop / tmin / 1e6:7.1f} TFLOP/s (staged K)", flush=True)
         for v in variants[1:]:
-            d = (outs[v] - outs[variants[0]]).abs().max().item()
+            d = (outs[v].float() - outs[variants[0]].float()).abs().max().item()
             print(f"    variant {v} vs {variants[0]}: max abs diff {d:.3e}")
         lib.pivlfn_conv_destroy(h)
     lib.pivlfn_tune(1, 0)
@@ -146,6 +159,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv"])
     ap.add_argument("--filter", default="")
+    ap.add_argument("--tune3", type=int, default=0, help="ablation mask of the fp16 conv kernel (pivlfn_tune(3, mask))")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
     ap.add_argument("--variants", default="1,2,0")
