@@ -20,6 +20,7 @@
 //   * workgroup ids are remapped so every XCD owns a contiguous band of tiles (halo re-reads hit its L2).
 #include <cstdlib>
 #include <hip/hip_ext.h>
+#include <algorithm>
 #include "common.h"
 
 namespace pivlfn {
@@ -406,8 +407,19 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rs, unsigned off)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
 }
 
-template <bool HASFLOW>
-__global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
+// R2 layouts (see WC3_DOTS_R2): with lane = (column ppx, row pair rp) the 16-lane groups of a ds_read_b128 span four row pairs,
+// so the quad swizzle of the warped tile keys on (r>>1)&3 instead of r&3, and the f1 tile's on the row-pair's upper bit.
+template <bool R2>
+__device__ __forceinline__ int swz_sel(int pos)
+{
+    if (!R2) return swz_pos(pos);
+    const int r = pos / TP, c = pos - r * TP;
+    return (((r >> 1) & 3) * 2 + ((c >> 1) & 1)) & 7;
+}
+__device__ __forceinline__ int swz_f1_r2(int fpp) { return ((fpp >> 1) & 3) | (((fpp >> 5) & 1) << 2); }
+
+template <bool HASFLOW, bool R2>
+__global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PP = 32, Q = 8;                  // unpadded 128-byte vectors, 16-byte quads XOR-swizzled (below)
@@ -465,9 +477,9 @@ __global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
     const unsigned rem_off = tid < 4 * REM ? tapo[(tid & 3) * NPOS + rem_pos] + 16u * rem_q : OOB;
     const float rem_w = tid < 4 * REM ? tapw[(tid & 3) * NPOS + rem_pos] : 0.f;
 
-    float acc[7];
+    float acc[R2 ? 14 : 7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) acc[k] = 0.f;
+    for (int k = 0; k < (R2 ? 14 : 7); ++k) acc[k] = 0.f;
     const int nch = p.C >> 5;
     f32x4 xa[3][NT];                  // gathered taps of this thread's three (position, quad) items
     f32x4 fa, ra;                     // f1 quad; remainder item (one TAP of one of the 32 left-over items, threads < 128)
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
             const int pos = pos0 + 64 * u;                                                        \
             f32x4 v = tapw[pos] * X[u][0];                                                        \
             _Pragma("unroll") for (int k = 1; k < NT; ++k) v += tapw[k * NPOS + pos] * X[u][k];   \
-            *reinterpret_cast<f32x4 *>(F2W + pos * PP + 4 * (q8 ^ swz_pos(pos))) = v;             \
+            *reinterpret_cast<f32x4 *>(F2W + pos * PP + 4 * (q8 ^ swz_sel<R2>(pos))) = v;         \
         }                                                                                         \
         if (grp < 2) {      /* waves 0,1: the 32 left-over items, one tap per lane, summed over each lane quad */ \
             f32x4 v = rem_w * XR;                                                                 \
@@ -503,9 +515,9 @@ __global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
                 v[e] += __shfl_xor(v[e], 1);                                                      \
                 v[e] += __shfl_xor(v[e], 2);                                                      \
             }                                                                                     \
-            if ((tid & 3) == 0) *reinterpret_cast<f32x4 *>(F2W + rem_pos * PP + 4 * (rem_q ^ swz_pos(rem_pos))) = v; \
+            if ((tid & 3) == 0) *reinterpret_cast<f32x4 *>(F2W + rem_pos * PP + 4 * (rem_q ^ swz_sel<R2>(rem_pos))) = v; \
         }                                                                                         \
-        *reinterpret_cast<f32x4 *>(F1T + fpp * PP + 4 * (q8 ^ ((fpp >> 1) & 7))) = XF;            \
+        *reinterpret_cast<f32x4 *>(F1T + fpp * PP + 4 * (q8 ^ (R2 ? swz_f1_r2(fpp) : ((fpp >> 1) & 7)))) = XF; \
     } while (0)
 
 #define WC3_DOTS(F2W, F1T)                                                                        \
@@ -538,6 +550,47 @@ __global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
         }                                                                                         \
     } while (0)
 
+
+// R2: a lane owns two vertically adjacent output pixels (rows 2rp, 2rp+1 of column ppx) and one 16-channel half of the chunk
+// (lanes 32-63 take the other half; summed across lane^32 once per tile); wave w < 7 owns the displacement column dx = w.
+// One 16-byte read of the warped tile at row 2rp+t feeds displacement dy = t of the upper pixel AND dy = t-1 of the lower:
+// 8 reads serve 14 displacement products (plus 2 reads for the two f1 quads), 40 reads per chunk and lane instead of 64,
+// so the dot products stop being bound by LDS read bandwidth.  The eighth wave only helps with staging.
+#define WC3_DOTS_R2(F2W, F1T)                                                                     \
+    do {                                                                                          \
+        if (grp < 7) {                                                                            \
+            int lane_l_ = lane;                                                                   \
+            asm volatile("" : "+v"(lane_l_));                                                     \
+            const int l5_ = lane_l_ & 31, hfs_ = lane_l_ >> 5;                                    \
+            const int ppx = l5_ & 7, rp = l5_ >> 3;                                               \
+            const int cx = ppx + grp;                                                             \
+            const int fp0 = 16 * rp + ppx;                                                        \
+            const int s1_ = swz_f1_r2(fp0);                 /* same for the pixel one row down */ \
+            const char *fb_ = reinterpret_cast<const char *>(F2W);                                \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                       \
+                const int qe = 4 * hfs_ + q;                                                      \
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(F1T + fp0 * PP + 4 * (qe ^ s1_)); \
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(F1T + (fp0 + 8) * PP + 4 * (qe ^ s1_)); \
+                _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                   \
+                    const int r = 2 * rp + t;                                                     \
+                    const unsigned sb = (unsigned)(r * TP + cx) * 128u + (unsigned)((qe ^ ((((r >> 1) & 3) * 2 + ((cx >> 1) & 1)) & 7)) << 4); \
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(fb_ + sb);                  \
+                    if (t < 7) {                                                                  \
+                        acc[t] = fmaf(a0[0], v0[0], acc[t]); acc[t] = fmaf(a0[1], v0[1], acc[t]); \
+                        acc[t] = fmaf(a0[2], v0[2], acc[t]); acc[t] = fmaf(a0[3], v0[3], acc[t]); \
+                        asm volatile("" : "+v"(acc[t]));                                          \
+                    }                                                                             \
+                    if (t > 0) {                                                                  \
+                        acc[6 + t] = fmaf(a1[0], v0[0], acc[6 + t]); acc[6 + t] = fmaf(a1[1], v0[1], acc[6 + t]); \
+                        acc[6 + t] = fmaf(a1[2], v0[2], acc[6 + t]); acc[6 + t] = fmaf(a1[3], v0[3], acc[6 + t]); \
+                        asm volatile("" : "+v"(acc[6 + t]));                                      \
+                    }                                                                             \
+                    if (t & 1) __builtin_amdgcn_sched_barrier(0);                                 \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
     WC3_ISSUE(xa, fa, ra, 0);
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
@@ -545,27 +598,50 @@ __global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
         WC3_COMMIT(xa, fa, ra, buf, (buf + NPOS * PP));            // waits for chunk c's loads, blends, writes LDS buffer c&1
         if (c + 1 < nch) WC3_ISSUE(xa, fa, ra, c + 1);             // next chunk in flight during the dot products below
         __syncthreads();     // buffer c&1 complete; every wave is past the dot products on buffer (c+1)&1
-        if (!(p.dbg & 1)) WC3_DOTS(buf, (buf + NPOS * PP));
+        if (!(p.dbg & 1)) {
+            if constexpr (R2) WC3_DOTS_R2(buf, (buf + NPOS * PP));
+            else WC3_DOTS(buf, (buf + NPOS * PP));
+        }
     }
 #undef WC3_COMMIT
 #undef WC3_DOTS
+#undef WC3_DOTS_R2
 #undef WC3_ISSUE
 
     __syncthreads();
     float *ost = smem;
     const float cf = (float)p.C;
+    if constexpr (R2) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const int d = grp + 8 * k;
-        if (d < 49) {
-            float v = acc[k] / cf;
-            if (p.leaky) v = lrelu01(v);
-            ost[lane * OUTC + d] = v;
+        for (int i = 0; i < 14; ++i) acc[i] += __shfl_xor(acc[i], 32);      // the two 16-channel halves
+        if (grp < 7 && lane < 32) {
+            const int fp0 = 16 * (lane >> 3) + (lane & 7);
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                float v0 = acc[t] / cf, v1 = acc[7 + t] / cf;
+                if (p.leaky) { v0 = lrelu01(v0); v1 = lrelu01(v1); }
+                ost[fp0 * OUTC + 7 * t + grp] = v0;
+                ost[(fp0 + 8) * OUTC + 7 * t + grp] = v1;
+            }
         }
-    }
-    if (grp == 0) {
+        if (grp == 7) {
 #pragma unroll
-        for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
+            for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int d = grp + 8 * k;
+            if (d < 49) {
+                float v = acc[k] / cf;
+                if (p.leaky) v = lrelu01(v);
+                ost[lane * OUTC + d] = v;
+            }
+        }
+        if (grp == 0) {
+#pragma unroll
+            for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < 64 * (OUTC / 4); idx += 512) {
@@ -577,23 +653,23 @@ __global__ __launch_bounds__(512) void warp_corr_v3_kernel(const WcParams p)
     }
 }
 
-template <bool HASFLOW>
+template <bool HASFLOW, bool R2>
 static int launch_wc3(const WcParams &p, hipStream_t st)
 {
     const size_t lds = ((size_t)2 * (NPOS + 64) * 32 + 8 * NPOS) * sizeof(float);
     PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
     static bool attr = false;
     if (!attr) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_v3_kernel<HASFLOW>),
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_v3_kernel<HASFLOW, R2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
     if (g_ev_start) {
-        hipExtLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW>), dim3(nblk), dim3(512), lds, st, g_ev_start, g_ev_stop, 0, p);
+        hipExtLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW, R2>), dim3(nblk), dim3(512), lds, st, g_ev_start, g_ev_stop, 0, p);
         g_ev_start = g_ev_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW>), dim3(nblk), dim3(512), lds, st, p);
+        hipLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW, R2>), dim3(nblk), dim3(512), lds, st, p);
     }
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
@@ -834,7 +910,8 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
         const long tiles = (long)cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * B;
         if ((variant == 0 && C % 64 == 0 && tiles <= 512) || (variant == 5 && C % 64 == 0))
             return flow ? launch_wc4<true>(p, st) : launch_wc4<false>(p, st);
-        if (variant == 0 || variant == 4 || variant == 5) return flow ? launch_wc3<true>(p, st) : launch_wc3<false>(p, st);
+        if (variant == 4) return flow ? launch_wc3<true, false>(p, st) : launch_wc3<false, false>(p, st);     // A/B: one pixel per lane
+        if (variant == 0 || variant == 5 || variant == 6) return flow ? launch_wc3<true, true>(p, st) : launch_wc3<false, true>(p, st);
         if (variant == 2) {                       // v2 with 4 waves
             if (C % 64 == 0) return flow ? launch_wc2<64, 4, true>(p, st) : launch_wc2<64, 4, false>(p, st);
             return flow ? launch_wc2<32, 4, true>(p, st) : launch_wc2<32, 4, false>(p, st);
