@@ -86,6 +86,38 @@ def cpu_baseline(model, size, wts, i1, i2):
                            f"slicing correlation), {dt:.2f} s"}
 
 
+def l3_throughput_regime(dev, batch=8, launches=40):
+    """The same level-3 warp+correlation kernel family outside the latency-bound batch-1 launch: batch 8 of the 1024x1024 level-3
+    shapes (2048 tiles), standalone through the C ABI on torch's current stream, timed with events around `launches` launches."""
+    from pivlfn import _lib
+    lib = _lib.load()
+    C, n, s = 64, 256, 2
+    g = torch.Generator(device=dev).manual_seed(7)
+    f1 = torch.randn(batch, n, n, C, device=dev, generator=g)
+    f2 = torch.randn(batch, n, n, C, device=dev, generator=g)
+    fl = torch.zeros(batch, n, n, 4, device=dev)
+    fl[..., :2] = torch.randn(batch, n, n, 2, device=dev, generator=g) * 0.8
+    out = torch.empty(batch, n // s, n // s, 56, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def launch():
+        _lib.check(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out.data_ptr(), batch, C, n, n, s, 1, st), "wc")
+    for _ in range(5):
+        launch()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(launches):
+        launch()
+    b.record()
+    torch.cuda.synchronize(dev)
+    t = a.elapsed_time(b) / launches * 1e-3
+    alg = l3_algorithmic_bytes(batch, 1024, 1024, 3, C, s)
+    return {"bound": "hbm", "achieved": round(alg / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / t / 8e12, 4),
+            "avg_launch_us": round(t * 1e6, 2), "algorithmic_bytes_per_launch": alg, "launches_timed": launches,
+            "workload": f"level-3 warp+correlation of batch {batch} x 1024x1024 (C=64, stride 2, 2048 tiles), back-to-back launches "
+                        "(launch gaps included)"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -204,6 +236,8 @@ def main():
                           "fp32_mfma_peak_tflops": 157.3,
                           "compute_frac": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None},
         }
+        if world == 1 and args.model == "piv" and S == 1024:
+            out["roofline_batch8"] = l3_throughput_regime(dev)
         if not args.no_cpu_baseline and world == 1:
             ref, cb = cpu_baseline(args.model, S, wts, i1c, i2c)
             out["cpu_baseline"] = cb
