@@ -92,6 +92,12 @@ struct ConvParams {
     int nchunk;         // K chunks of 8 input channels over all segments (the last one may be a 4-channel tail)
     int tail;           // 1 when the last chunk is a 4-channel tail (last source has cload % 8 == 4)
     int lrelu;
+    // split-K for layers with too few tiles to fill the chip (the coarse pyramid levels): gridDim.z workgroups share a tile,
+    // each contracts a contiguous range of K chunks into scratch[z][pixel][cout_pad]; conv_splitk_reduce_kernel adds the
+    // partial sums in z order (deterministic), then bias / residual / activation.  scratch == nullptr: never split.
+    float *scratch;
+    size_t scratch_floats;
+    int ksplit;         // number of K shares (set by the launcher; 0/1 = no split)
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);

@@ -213,9 +213,18 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
     const size_t wchunk = (size_t)taps * 2 * p.cout_pad;
 
     f32x4 pr[PMAX], wr[WMAX];
-    int seg = 0, c0 = 0;
-    const float *sp = p.seg[0].ptr;
-    int scl = p.seg[0].cload, sst = p.seg[0].stride;
+    // this workgroup's K range: all chunks, or with split-K (gridDim.z > 1) an even share of the full chunks; the 4-channel
+    // tail chunk, if any, goes to the last share
+    const int nfull = p.nchunk - p.tail;
+    const int nz = gridDim.z, kz = blockIdx.z;
+    const int per = (nfull + nz - 1) / nz;
+    const int kc0 = min(nfull, kz * per), kc1 = min(nfull, kc0 + per);
+    const bool has_tail = p.tail && kz == nz - 1;
+    const int kend = kc1 + (has_tail ? 1 : 0);
+    int seg = 0, c0 = kc0 * 8;
+    while (seg + 1 < p.nseg && c0 >= p.seg[seg].cload) { c0 -= (p.seg[seg].cload + 7) / 8 * 8; ++seg; }
+    const float *sp = p.seg[seg].ptr;
+    int scl = p.seg[seg].cload, sst = p.seg[seg].stride;
 
 #define CONV2_LOAD(CH)                                                                            \
     do {                                                                                          \
@@ -233,9 +242,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
     // K loop.  A source whose channel count is 4 (mod 8) ends in a half chunk; the packer only allows that for the LAST
     // source, so the tail is peeled: the hot loop below stays branch-free, and the tail contracts its 4 channels with two
     // MFMAs per tap (k = {j, 2+j}; staged as [c0 c1 c2 c3 | c2 c3 0 0] so both lane halves read their pair at j = 0, 1).
-    const int nfull = p.nchunk - p.tail;
-    CONV2_LOAD(0);
-    for (int chunk = 0; chunk < nfull; ++chunk) {
+    if (kc0 < kend) CONV2_LOAD(kc0);
+    for (int chunk = kc0; chunk < kc1; ++chunk) {
         // registers -> LDS (waits for the loads of this chunk)
 #pragma unroll
         for (int i = 0; i < PMAX; ++i)
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
             if (woff[i] >= 0) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
         __syncthreads();
         // advance to the next chunk's source and put its loads in flight
-        if (chunk + 1 < p.nchunk) {
+        if (chunk + 1 < kend) {
             c0 += 8;
             if (c0 >= scl) {
                 ++seg;
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
         }
         __syncthreads();       // all waves done with this chunk's LDS image before it is overwritten
     }
-    if (p.tail) {
+    if (has_tail) {
 #pragma unroll
         for (int i = 0; i < PMAX; ++i)
             if (plds[i] >= 0) {
@@ -312,7 +320,22 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
     // Epilogue.  With A = weights and B = pixels the accumulator tile is D[channel][pixel]: lane&31 = pixel, and registers
     // 4g..4g+3 hold channels 8g + 4*hh + {0,1,2,3} -- four consecutive channels per lane, so bias / residual / output move
     // as 16-byte vectors: 32 stores per thread for a 64x128 wave tile instead of 128, and a quarter of the address math.
-    {
+    if (nz > 1) {       // split-K: raw partial sums, every channel of the padded N block, to scratch[kz][pixel][cout_pad]
+        const int ox = x0 + row;
+        const size_t npix = (size_t)p.B * p.Ho * p.Wo;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + wave * MT + m;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            float *prow = p.scratch + ((size_t)kz * npix + (size_t)(b * p.Ho + oy) * p.Wo + ox) * p.cout_pad + n0;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4 *>(prow + n * 32 + 8 * g + 4 * hh) =
+                        f32x4{acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+        }
+    } else {
         const int ox = x0 + row;
         const bool interior = x0 + 32 <= p.Wo && y0 + TH <= p.Ho && n0 + BN <= p.cout_store;   // workgroup-uniform fast path
 #pragma unroll
@@ -341,6 +364,26 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
     }
 }
 
+// Second pass of a split-K layer: out = act(bias + residual + sum_z scratch[z]), z ascending (deterministic), 4 channels per thread.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p, int nz)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cq = p.cout_pad / 4;
+    const long npix = (long)p.B * p.Ho * p.Wo;
+    if (idx >= npix * cq) return;
+    const long pix = idx / cq;
+    const int ch = (int)(idx - pix * cq) * 4;
+    if (ch >= p.cout_store) return;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(p.scratch + (size_t)pix * p.cout_pad + ch);
+    for (int z = 1; z < nz; ++z) v += *reinterpret_cast<const f32x4 *>(p.scratch + ((size_t)z * npix + pix) * p.cout_pad + ch);
+    v += *reinterpret_cast<const f32x4 *>(p.bias + ch);
+    if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (size_t)pix * p.res_stride + ch);
+    if (p.lrelu) {
+        v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+    }
+    *reinterpret_cast<f32x4 *>(p.out + (size_t)pix * p.out_stride + ch) = v;
+}
+
 template <int MT, int NT, int PMAX, int WMAX>
 static int launch_t2(const ConvParams &p, hipStream_t st)
 {
@@ -356,16 +399,35 @@ static int launch_t2(const ConvParams &p, hipStream_t st)
         attr_set = true;
     }
     const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
-    dim3 grid(tiles, p.cout_pad / BN);
+    const int nz = p.ksplit > 1 ? p.ksplit : 1;
+    dim3 grid(tiles, p.cout_pad / BN, nz);
     hipLaunchKernelGGL((conv_mfma2_kernel<MT, NT, PMAX, WMAX>), grid, dim3(256), lds, st, p);
     PIV_CHECK_HIP(hipGetLastError());
+    if (nz > 1) {
+        const long items = (long)p.B * p.Ho * p.Wo * (p.cout_pad / 4);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, nz);
+        PIV_CHECK_HIP(hipGetLastError());
+    }
     return PIVLFN_OK;
 }
 
 // Tile choice for v2.  Staging loads per thread: patch = PH*PW*2/256, slab = taps*2*BN/256 (16-byte each).
-static int launch_conv2(const ConvParams &p, hipStream_t st)
+static int launch_conv2(const ConvParams &p_in, hipStream_t st)
 {
+    ConvParams p = p_in;
     const int taps = p.KH * p.KW;
+    // Split-K when one image has too few tiles for the chip and the K loop is long enough to be worth sharing.  Decided from
+    // the per-image count of canonical (4 rows x 32 px x 32 channels) tiles only -- never from the batch size or from the tile
+    // shape picked below (which does depend on it): a pair's flow must not depend on its batch mates, bit for bit.
+    {
+        const int nfull = p.nchunk - p.tail;
+        const long blocks1 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 4) * (p.cout_pad / 32);
+        p.ksplit = 1;
+        if (p.scratch && blocks1 <= 128 && nfull >= 4 && !(g_knob[1] & 128)) {
+            p.ksplit = (int)std::min<long>(std::min(8, nfull / 2), std::max<long>(1, 512 / blocks1));
+            if ((size_t)p.B * p.Ho * p.Wo * p.cout_pad * p.ksplit > p.scratch_floats) p.ksplit = 1;   // standalone layers with a small scratch only
+        }
+    }
     const long px_blocks1 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 4) * p.B;     // workgroups with MT = 1 per N block
     // widest N tile (32*nt channels) that still leaves >= 256 workgroups; with fewer the tile is narrowed so more CUs get
     // work (the input patch is then re-staged once per N block, which is cheap at the small levels where this happens)

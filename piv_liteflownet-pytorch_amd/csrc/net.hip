@@ -15,6 +15,10 @@ static const int C_MATCH[7] = {0, 64, 64, 64, 96, 128, 192};    // NetC_ext: src
 
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 
+// Split-K scratch (conv_mfma.hip): a layer is split only when one image has <= 128 workgroups of 128 px x 32 channels, i.e. at
+// most 128*128*32 partial sums per share and image, and into at most 8 shares.
+static const size_t KSPLIT_FLOATS = (size_t)8 * 128 * 128 * 32;
+
 void pack_conv_h(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
                  std::vector<unsigned short> &pk, int *nchunk_out);      // conv_f16.hip
 
@@ -40,6 +44,7 @@ struct pivlfn_net;
 struct pivlfn_conv {
     pivlfn::ConvW cw;
     int cin = 0;
+    float *scratch = nullptr;  // split-K scratch (KSPLIT_FLOATS), allocated by conv_create
     float *head = nullptr;     // set when the layer is a 32->2 kxk flow head
     float hb[2] = {0.f, 0.f};
     pivlfn_net *owner = nullptr;   // holds the device allocations
@@ -348,6 +353,11 @@ int conv_create(const float *weight, const float *bias, int cout, int cin, int k
     c->cin = cin;
     int rc = pack_conv(c->owner, m, "c", cout, cin, kh, kw, {{cin, rup(cin, 4)}}, &c->cw);
     if (!rc && cout == 2 && cin == 32 && kh == kw && (kh == 3 || kh == 5 || kh == 7)) rc = pack_head(c->owner, m, "c", kh, &c->head, c->hb);
+    if (!rc) {
+        void *d = nullptr;
+        if (hipMalloc(&d, KSPLIT_FLOATS * sizeof(float)) != hipSuccess) { set_error("conv_create: scratch allocation failed"); rc = PIVLFN_ERR_HIP; }
+        else { c->owner->allocs.push_back(d); c->scratch = (float *)d; }
+    }
     if (rc) { net_destroy(c->owner); delete c; return rc; }
     *out = c;
     return PIVLFN_OK;
@@ -379,6 +389,7 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
     p.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
     p.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
     p.nchunk = c->cw.nchunk; p.tail = c->cw.tail; p.lrelu = leaky;
+    p.scratch = c->scratch; p.scratch_floats = KSPLIT_FLOATS;
     return launch_conv(p, st);
 }
 
@@ -403,7 +414,7 @@ struct Plan {
 struct Buffers {
     float *img[7], *feat[7], *ext[3], *sa, *sb;
     float *flowA, *flowB, *flow_up, *flowM, *flowS, *corr, *corr_up, *t128a, *t128b, *t64a, *t64b, *t32a, *t32b,
-        *f2w, *featR[7], *misc4, *d1, *dist, *partial, *mean;
+        *f2w, *featR[7], *misc4, *d1, *dist, *partial, *mean, *ksplit;
 };
 
 static void plan(const pivlfn_net *net, int B, int H, int W, Plan &pl, Buffers &bf)
@@ -430,6 +441,7 @@ static void plan(const pivlfn_net *net, int B, int H, int W, Plan &pl, Buffers &
     for (int L = 1; L <= 6; ++L) bf.featR[L] = (L >= ll && L < 5) ? pl.take((size_t)B * h[L] * w[L] * 128) : nullptr;   // one per level: filled on the side stream
     bf.misc4 = pl.take(px * 4);
     bf.d1 = pl.take(px * 56); bf.dist = pl.take(px * 56);
+    bf.ksplit = pl.take(KSPLIT_FLOATS * 2 * B);     // per image (NetC runs 2B images): the split never depends on the batch
     bf.partial = pl.take((size_t)B * flow_mean_partials(0) * 2);
     bf.mean = pl.take((size_t)B * 2);
 }
@@ -449,6 +461,8 @@ size_t net_levels_floats(const pivlfn_net *net, int B, int H, int W)
 }
 
 static thread_local int t_precision = 0;      // set by net_forward for the duration of one forward
+static thread_local float *t_scratch = nullptr;          // split-K scratch of the forward in progress (main stream only)
+static thread_local hipStream_t t_side = nullptr;
 
 static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out, int out_stride, int cout_store,
                 const float *res, int res_stride, int lrelu, int B, int H, int W, int S, int padY, int padX, hipStream_t st)
@@ -481,6 +495,8 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
     p.Ho = Ho;
     p.Wo = Wo;
     p.nchunk = cw.nchunk; p.tail = cw.tail; p.lrelu = lrelu;
+    p.scratch = (t_side && st == t_side) ? nullptr : t_scratch;      // one scratch area: the side stream never splits
+    p.scratch_floats = KSPLIT_FLOATS * B;
     return launch_conv(p, st);
 }
 
@@ -522,6 +538,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
                 "forward: H=%d W=%d must be positive multiples of 32 (use estimate() for other sizes)", H, W);
     PIV_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "forward: workspace must be 256-byte aligned");
     t_precision = net->precision;
+    t_side = net->side;
     Plan pl; Buffers bf;
     pl.base = reinterpret_cast<char *>(ws);
     plan(net, B, H, W, pl, bf);
@@ -532,6 +549,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     int h[7], w[7];
     for (int L = 1; L <= 6; ++L) { h[L] = H >> (L - 1); w[L] = W >> (L - 1); }
     const int N2 = 2 * B;
+    t_scratch = bf.ksplit;
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
     // mean subtraction + layout change (:321-323), image pyramid (:336-343)
     RUN(launch_prep_images(img1, img2, bf.img[1], B, H, W, net->mean, st));
