@@ -99,6 +99,8 @@ def test_batch_consistency_and_argument_errors(nets, dev):
     for k in range(3):
         one = nets["piv"](i1[k:k + 1], i2[k:k + 1])
         assert torch.equal(one[0], full[k])                   # every pair is independent of its batch mates
+    # (bit-for-bit as long as the batch does not move a level's warp+correlation launch between the latency and the throughput
+    #  variant of the kernel -- the conv split-K factor never depends on the batch; the next test bounds the other case)
     with pytest.raises(ValueError):
         nets["piv"](i1[:, :, :50], i2[:, :, :50])            # not a multiple of 32 -> estimate() territory
     with pytest.raises(ValueError):
@@ -107,6 +109,20 @@ def test_batch_consistency_and_argument_errors(nets, dev):
     with pytest.raises(NotImplementedError):
         nets["piv"](i1, i2)
     nets["piv"].eval()
+
+
+def test_batch_consistency_across_kernel_variants(nets, dev):
+    """A batch large enough to switch the warp+correlation launches of several levels to the throughput variant (different
+    fp32 summation order): every pair still equals its single-pair result to a few 1e-6 px (tools/big_batch_check.py measures
+    3e-6 px at 32 x 512x512 and 8 x 1024x1024)."""
+    a, b = synth.particle_batch(2, 256, 256, seed=32)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    single = torch.cat([nets["piv"](i1[k:k + 1], i2[k:k + 1]) for k in range(2)])
+    B = 24
+    big = nets["piv"](torch.stack([i1[k % 2] for k in range(B)]), torch.stack([i2[k % 2] for k in range(B)]))
+    for k in range(B):
+        assert (big[k] - single[k % 2]).abs().max().item() <= 2e-5 * max(1.0, single.abs().max().item())
+    assert torch.equal(big[0], big[2]) and torch.equal(big[1], big[23])     # identical pairs in one batch: identical flows
 
 
 def test_reloading_weights_takes_effect(dev):
