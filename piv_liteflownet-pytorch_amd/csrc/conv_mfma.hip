@@ -411,6 +411,144 @@ static int launch_t2(const ConvParams &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
+// ---- single-chunk layers with many taps (NetC.conv1: 7x7, 3 -> 32): weights resident, persistent over tiles ------------------
+// With K = one 4-channel tail chunk the v2 kernel restages the whole weight slab (49 taps x 32 channels x 32 bytes = 50 KB)
+// for every 8x32-pixel tile against 8.5 KB of input patch: the layer runs at the CU's load-path limit (57 TFLOP/s), not at the
+// matrix pipe's.  Here a workgroup stages the slab once and walks tiles blockIdx.x, +gridDim.x, ...; the next tile's patch
+// is prefetched into registers under the current tile's 196 MFMAs per wave.  Same arithmetic and k order as v2's tail path
+// (patch staged as [c0 c1 c2 c3 | c2 c3 0 0], two MFMAs per tap), so the results are bit-identical.
+template <int PMAX>
+__global__ __launch_bounds__(256, 2) void conv_k1_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MT = 2, TH = 8, BN = 32;
+    const int taps = p.KH * p.KW;
+    const int PH = (TH - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
+    float *patch = smem;
+    float *wts = smem + PH * PW * PIXP;
+    const int tiles_x = (p.Wo + 31) >> 5, tiles_y = (p.Ho + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * p.B;
+    const int n0 = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, hh = lane >> 5;
+    if ((int)blockIdx.x >= ntiles) return;
+
+    // weight slab -> LDS, once
+    {
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + n0;
+        for (int idx = tid; idx < taps * 2 * BN; idx += 256)
+            reinterpret_cast<f32x4 *>(wts)[idx] = wsrc[(idx / BN) * p.cout_pad + (idx % BN)];
+    }
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = ((wave * MT + m) * p.S * PW + row * p.S) * PIXP + hh * 4;
+    const int bbase = (hh * BN + row) * 4;
+    const int npix2 = PH * PW * 2;
+    const int q4 = (tid & 1) * 4;
+    const float *sp = p.seg[0].ptr;
+    const int sst = p.seg[0].stride;
+    const f32x4 bias4[4] = {*reinterpret_cast<const f32x4 *>(p.bias + n0 + 4 * hh), *reinterpret_cast<const f32x4 *>(p.bias + n0 + 8 + 4 * hh),
+                            *reinterpret_cast<const f32x4 *>(p.bias + n0 + 16 + 4 * hh), *reinterpret_cast<const f32x4 *>(p.bias + n0 + 24 + 4 * hh)};
+
+    f32x4 pr[PMAX];
+#define K1_LOAD(T)                                                                                \
+    do {                                                                                          \
+        int t_ = (T);                                                                             \
+        const int tx_ = t_ % tiles_x;                                                             \
+        t_ /= tiles_x;                                                                            \
+        const int b_ = t_ / tiles_y;                                                              \
+        const int ix0_ = tx_ * 32 * p.S - p.padX, iy0_ = (t_ - b_ * tiles_y) * TH * p.S - p.padY; \
+        _Pragma("unroll") for (int i = 0; i < PMAX; ++i) {                                        \
+            const int idx_ = tid + 256 * i, pix_ = idx_ >> 1;                                     \
+            const int py_ = pix_ / PW, px_ = pix_ - py_ * PW;                                     \
+            const int iy_ = iy0_ + py_, ix_ = ix0_ + px_;                                         \
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                       \
+            if (idx_ < npix2 && iy_ >= 0 && iy_ < p.H && ix_ >= 0 && ix_ < p.W)                   \
+                v = *reinterpret_cast<const f32x4 *>(sp + (size_t)((b_ * p.H + iy_) * p.W + ix_) * sst); \
+            pr[i] = v;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+    K1_LOAD(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();          // previous tile's operand reads are done (first pass: nothing to wait for)
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < npix2) {
+                f32x4 v = pr[i];
+                if (q4) v = f32x4{v[2], v[3], 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(patch + (idx >> 1) * PIXP + q4) = v;
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) K1_LOAD(tile + gridDim.x);
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        int tap = 0;
+        for (int ky = 0; ky < p.KH; ++ky)
+            for (int kx = 0; kx < p.KW; ++kx, ++tap) {
+                const int toff = (ky * PW + kx) * PIXP;
+                f32x2 a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x2 *>(patch + abase[m] + toff);
+                const f32x2 bq = *reinterpret_cast<const f32x2 *>(wts + tap * 2 * BN * 4 + bbase);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[j], a[m][j], acc[m], 0, 0, 0);
+            }
+        // epilogue (same lane layout as v2): 4 consecutive channels per lane and register group
+        int t_ = tile;
+        const int tx = t_ % tiles_x;
+        t_ /= tiles_x;
+        const int b = t_ / tiles_y;
+        const int x0 = tx * 32, y0 = (t_ - b * tiles_y) * TH;
+        const int ox = x0 + row;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + wave * MT + m;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            float *orow = p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.out_stride + n0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (n0 + 8 * g + 4 * hh >= p.cout_store) continue;
+                f32x4 v = {acc[m][4 * g + 0], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+                v += bias4[g];
+                if (p.lrelu) {
+                    v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                }
+                *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * hh) = v;
+            }
+        }
+    }
+#undef K1_LOAD
+}
+
+// Applies to: one K chunk that is a 4-channel tail, >= 16 taps, no residual, 32-channel output blocks, enough tiles.
+static int launch_conv_k1(const ConvParams &p, hipStream_t st)
+{
+    if (p.nchunk != 1 || !p.tail || p.res || p.KH * p.KW < 16 || p.nseg != 1 || (g_knob[1] & 256)) return -1;
+    const int PH = 7 * p.S + p.KH, PW = 31 * p.S + p.KW;
+    if (PH * PW * 2 > 256 * 5) return -1;
+    const size_t lds = ((size_t)PH * PW * PIXP + (size_t)p.KH * p.KW * 2 * 32 * 4) * sizeof(float);
+    if (lds > 80 * 1024) return -1;
+    const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B;
+    if (tiles < 1024) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_k1_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+        attr_set = true;
+    }
+    const int nby = p.cout_pad / 32;
+    hipLaunchKernelGGL((conv_k1_kernel<5>), dim3(std::max(1, 512 / nby), nby), dim3(256), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
 // Tile choice for v2.  Staging loads per thread: patch = PH*PW*2/256, slab = taps*2*BN/256 (16-byte each).
 static int launch_conv2(const ConvParams &p_in, hipStream_t st)
 {
@@ -496,6 +634,8 @@ int launch_conv(const ConvParams &p, hipStream_t st)
     for (int s = 0; s < p.nseg; ++s)
         PIV_REQUIRE(p.seg[s].cload % 4 == 0 && p.seg[s].stride % 4 == 0 && p.seg[s].ptr, "conv: segment %d misaligned", s);
     if (!(g_knob[1] & 2)) {               // shipped path: v2 (register prefetch); knob bit 1 forces v1 for A/B
+        const int rk = launch_conv_k1(p, st);
+        if (rk >= 0) return rk;
         const int rc = launch_conv2(p, st);
         if (rc >= 0) return rc;
     }
