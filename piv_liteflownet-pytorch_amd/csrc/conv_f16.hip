@@ -24,6 +24,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HPITCH = 24;      // halfs per staged pixel (16 channels + 8 of padding = 48 bytes)
 
@@ -189,6 +191,39 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
             const int oy = y0 + wave * MT + m;
             const bool pix_ok = interior || (oy < p.Ho && ox < p.Wo);
             const size_t pix = (size_t)(b * p.Ho + (oy < p.Ho ? oy : 0)) * p.Wo + (ox < p.Wo ? ox : 0);
+            if (p.out_f16) {
+                // fp16 output: a lane's 4 channels are only 8 bytes.  Lanes l and l+32 hold the two halves of the same
+                // 8-channel group of the same pixel, so one v_permlane32_swap per register pairs them up: the lower lane
+                // stores channels 8g..8g+7 of the even group, the upper lane those of the odd group -- 16-byte stores.
+                _Float16 *orow = reinterpret_cast<_Float16 *>(p.out) + pix * p.out_stride;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned w[2][2];        // [group parity][dword] = this lane's 4 channels of groups 2gp and 2gp+1, as fp16
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int g = 2 * gp + e;
+                            f32x4 v = {acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                            v += *reinterpret_cast<const f32x4 *>(lbias + n * 32 + 8 * g + 4 * hh);
+                            if (p.lrelu) {
+                                v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                            }
+                            const h4 hv = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            __builtin_memcpy(w[e], &hv, 8);
+                        }
+                        // after the swaps: lower lanes hold (own even group, partner's even group), upper lanes (partner's odd, own odd)
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                        const int ch = n0 + n * 32 + 16 * gp + 8 * hh;      // first of this lane's 8 channels
+                        if (!pix_ok || (!interior && ch >= p.cout_store)) continue;
+                        const u32x4 q = {s0[0], s1[0], s0[1], s1[1]};
+                        if (interior || ch + 8 <= p.cout_store) *reinterpret_cast<u32x4 *>(orow + ch) = q;
+                        else *reinterpret_cast<u32x2 *>(orow + ch) = u32x2{q[0], q[1]};
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -200,11 +235,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
                     if (p.lrelu) {
                         v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
                     }
-                    if (p.out_f16)
-                        *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(p.out) + pix * p.out_stride + ch) =
-                            h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    else
-                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + pix * p.out_stride + ch) = v;
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out) + pix * p.out_stride + ch) = v;
                 }
             }
         }

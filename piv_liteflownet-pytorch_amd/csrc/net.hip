@@ -464,8 +464,11 @@ static thread_local int t_precision = 0;      // set by net_forward for the dura
 static thread_local float *t_scratch = nullptr;          // split-K scratch of the forward in progress (main stream only)
 static thread_local hipStream_t t_side = nullptr;
 
+// in16: bit i set = source i holds fp16 elements; out16: the output is stored as fp16.  Both are only ever non-zero for layers
+// that run on the fp16 kernel (net_forward's `h16` uses the same size test as below).
 static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out, int out_stride, int cout_store,
-                const float *res, int res_stride, int lrelu, int B, int H, int W, int S, int padY, int padX, hipStream_t st)
+                const float *res, int res_stride, int lrelu, int B, int H, int W, int S, int padY, int padX, hipStream_t st,
+                int in16 = 0, int out16 = 0)
 {
     const int Ho = (H + 2 * padY - cw.KH) / S + 1, Wo = (W + 2 * padX - cw.KW) / S + 1;
     // fp16 mode: every residual-free conv whose output grid is at least 64x64 (smaller levels are launch-latency-bound and
@@ -474,15 +477,16 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         ConvParamsH q;
         memset(&q, 0, sizeof(q));
         int i = 0;
-        for (auto &sg : segs) q.seg[i++] = ConvSegH{sg.ptr, sg.cload, sg.stride, 0};
+        for (auto &sg : segs) { q.seg[i] = ConvSegH{sg.ptr, sg.cload, sg.stride, (in16 >> i) & 1}; ++i; }
         q.nseg = i;
         q.wpk = cw.wpk_h; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
-        q.cout_pad = cw.cout_pad; q.out_f16 = 0;
+        q.cout_pad = cw.cout_pad; q.out_f16 = out16;
         q.B = B; q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
         q.KH = cw.KH; q.KW = cw.KW; q.S = S; q.padY = padY; q.padX = padX;
         q.nchunk = cw.nchunk_h; q.lrelu = lrelu;
         return launch_conv_h(q, st);
     }
+    PIV_REQUIRE(!in16 && !out16, "internal: fp16 activations routed to the fp32 conv kernel");
     ConvParams p;
     memset(&p, 0, sizeof(p));
     int i = 0;
@@ -595,6 +599,8 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         const float *im1 = bf.img[L], *im2 = bf.img[L] + half * 4;
         const float sc = net->scale[L];
         const int s = L >= 4 ? 1 : 2;
+        // fp16 mode: the hidden activations of this level's conv stacks are stored as fp16 (same size test as conv())
+        const int h16 = (t_precision == 1 && (long)hh * ww >= 64 * 64) ? 1 : 0;
         // Join the side stream only where its results are first read: NetC_ext feeds Matching at levels <= 2, moduleFeat feeds
         // Regularization at levels 3 and 4.  (A cross-queue wait costs a barrier packet and a cold start for the next
         // kernel: in front of the level-3 warp+correlation it cost that launch 2 us.)
@@ -629,8 +635,9 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             for (int j = 0; j < net->nstack; ++j) {
                 const int wd = net->width[j];
                 float *dst = (j & 1) ? bf.t128b : bf.t128a;
-                if (j == 0) RUN(conv(lw.M[0], {{src, 52, 56}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-                else RUN(conv(lw.M[j], {{src, cprev, cprev}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+                const int o16 = (j + 1 < net->nstack) ? h16 : 0;      // the flow head reads fp32
+                if (j == 0) RUN(conv(lw.M[0], {{src, 52, 56}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, 0, o16));
+                else RUN(conv(lw.M[j], {{src, cprev, cprev}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, h16, o16));
                 src = dst;
                 cprev = wd;
             }
@@ -648,8 +655,9 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             for (int j = 0; j < net->nstack; ++j) {
                 const int wd = net->width[j];
                 float *dst = (j & 1) ? bf.t128b : bf.t128a;
-                if (j == 0) RUN(conv(lw.S[0], {{f1m, cm, cm}, {bf.f2w, cm, cm}, {bf.flowM, 4, 4}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-                else RUN(conv(lw.S[j], {{src, cprev, cprev}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+                const int o16 = (j + 1 < net->nstack) ? h16 : 0;
+                if (j == 0) RUN(conv(lw.S[0], {{f1m, cm, cm}, {bf.f2w, cm, cm}, {bf.flowM, 4, 4}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, 0, o16));
+                else RUN(conv(lw.S[j], {{src, cprev, cprev}}, dst, wd, wd, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, h16, o16));
                 src = dst;
                 cprev = wd;
             }
@@ -665,18 +673,18 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         if (L == 3 || L == 4) PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0));
         const float *fr = L < 5 ? bf.featR[L] : f1raw;
         const int cfr = L < 5 ? 128 : cf;
-        RUN(conv(lw.R[0], {{fr, cfr, cfr}, {bf.misc4, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.R[1], {{bf.t128a, 128, 128}}, bf.t128b, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.R[2], {{bf.t128b, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.R[3], {{bf.t64a, 64, 64}}, bf.t64b, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.R[4], {{bf.t64b, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
-        RUN(conv(lw.R[5], {{bf.t32a, 32, 32}}, bf.t32b, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st));
+        RUN(conv(lw.R[0], {{fr, cfr, cfr}, {bf.misc4, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, 0, h16));
+        RUN(conv(lw.R[1], {{bf.t128a, 128, 128}}, bf.t128b, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, h16, h16));
+        RUN(conv(lw.R[2], {{bf.t128b, 128, 128}}, bf.t64a, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, h16, h16));
+        RUN(conv(lw.R[3], {{bf.t64a, 64, 64}}, bf.t64b, 64, 64, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, h16, h16));
+        RUN(conv(lw.R[4], {{bf.t64b, 64, 64}}, bf.t32a, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, h16, h16));
+        RUN(conv(lw.R[5], {{bf.t32a, 32, 32}}, bf.t32b, 32, 32, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, h16, h16));
         const int kk = k * k, kkp = rup(kk, 4);
-        if (L < 5) {     // (k x 1) then (1 x k), no activation in between (:253-261)
-            RUN(conv(lw.dist0, {{bf.t32b, 32, 32}}, bf.d1, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, k / 2, 0, st));
+        if (L < 5) {     // (k x 1) then (1 x k), no activation in between (:253-261); d1 and dist stay fp32
+            RUN(conv(lw.dist0, {{bf.t32b, 32, 32}}, bf.d1, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, k / 2, 0, st, h16, 0));
             RUN(conv(lw.dist1, {{bf.d1, kkp, kkp}}, bf.dist, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, 0, k / 2, st));
         } else {
-            RUN(conv(lw.dist0, {{bf.t32b, 32, 32}}, bf.dist, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, k / 2, k / 2, st));
+            RUN(conv(lw.dist0, {{bf.t32b, 32, 32}}, bf.dist, kkp, kkp, nullptr, 0, 0, B, hh, ww, 1, k / 2, k / 2, st, h16, 0));
         }
         const bool last = L == net->lowest;
         RUN(launch_reg_tail(bf.dist, kkp, bf.flowS, lw.wx, lw.wy, lw.bx, lw.by, k, cur, last ? flow : nullptr,
