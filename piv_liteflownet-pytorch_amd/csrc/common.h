@@ -120,6 +120,7 @@ struct ConvParamsH {
     int KH, KW, S, padY, padX;
     int nchunk, lrelu;
     int dbg;            // ablation mask for tools/bench_ops.py (0 in production): 1 no MFMAs, 2 no global loads, 4 no LDS commit
+    unsigned long long *stamps;   // tools only: per-workgroup phase times (s_memtime ticks), 8 per workgroup; nullptr in production
 };
 int launch_conv_h(const ConvParamsH &p, hipStream_t st);
 // 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device

@@ -125,6 +125,18 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
         }                                                                                         \
     } while (0)
 
+    // phase stamps (tools/bench_ops.py conv_stamps): wave 0 accumulates where its time goes
+    const bool stamp = p.stamps != nullptr && wave == 0 && blockIdx.y == 0;
+    unsigned long long tk = 0, d_commit = 0, d_bar1 = 0, d_issue = 0, d_taps = 0, d_bar2 = 0, t_begin = 0;
+#define STAMP(ACC)                                                                                \
+    do {                                                                                          \
+        if (stamp) {                                                                              \
+            const unsigned long long now_ = __builtin_readcyclecounter();                         \
+            ACC += now_ - tk;                                                                     \
+            tk = now_;                                                                            \
+        }                                                                                         \
+    } while (0)
+    if (stamp) t_begin = tk = __builtin_readcyclecounter();
     CH_LOAD(0);
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         // registers -> LDS (waits for this chunk's loads), converting fp32 sources to fp16
@@ -149,7 +161,9 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
             for (int i = 0; i < WM; ++i)
                 if (tid + 256 * i < nw) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
         }
+        STAMP(d_commit);
         __syncthreads();
+        STAMP(d_bar1);
         if (chunk + 1 < p.nchunk) {
             c0 += 16;
             if (c0 >= scl) {
@@ -160,6 +174,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
             }
             CH_LOAD(chunk + 1);
         }
+        STAMP(d_issue);
         int tap = 0;
         for (int ky = 0; ky < ((p.dbg & 1) ? 0 : p.KH); ++ky) {
             for (int kx = 0; kx < p.KW; ++kx, ++tap) {
@@ -176,9 +191,13 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[n], a[m], acc[m][n], 0, 0, 0);   // A = channels, B = pixels
             }
         }
+        STAMP(d_taps);
         __syncthreads();
+        STAMP(d_bar2);
     }
 #undef CH_LOAD
+    unsigned long long t_loop_end = 0;
+    if (stamp) t_loop_end = __builtin_readcyclecounter();
 
     // Epilogue: lane&31 = pixel, registers 4g..4g+3 = channels 8g + 4*hh + {0..3} (same D layout as the fp32 kernel).
     // The bias comes from LDS: with the whole register file in use the 32 per-store global bias loads of the fp32 kernel's
@@ -240,6 +259,15 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
             }
         }
     }
+    if (stamp && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 8;
+        o[0] = d_commit; o[1] = d_bar1; o[2] = d_issue; o[3] = d_taps; o[4] = d_bar2;
+        o[5] = t_end - t_loop_end;       // epilogue
+        o[6] = t_end - t_begin;          // whole workgroup
+        o[7] = t_begin;
+    }
+#undef STAMP
 }
 
 template <int MT, int NT, int PM, int WM>
@@ -267,6 +295,7 @@ int launch_conv_h(const ConvParamsH &p_in, hipStream_t st)
 {
     ConvParamsH p = p_in;
     p.dbg = g_knob[3];
+    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)g_knob[6] << 32) | (unsigned)g_knob[5]);   // tools only
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.nchunk >= 1, "conv_f16: bad segment description");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0, "conv_f16: bad output channel counts");
     for (int i = 0; i < p.nseg; ++i)

@@ -155,9 +155,55 @@ def bench_conv(args):
     lib.pivlfn_tune(1, 0)
 
 
+def bench_conv_stamps(args):
+    """Phase times of the fp16 conv kernel (wave 0 of every workgroup, s_memtime ticks): where a workgroup's time goes."""
+    import ctypes
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for name, co, ci, k, s, n, bm in CONV_SHAPES:
+        if args.filter and args.filter not in name:
+            continue
+        kh, kw = (k, k) if isinstance(k, int) else k
+        B = args.batch * bm
+        w = (torch.randn(co, ci, kh, kw) / (ci * kh * kw) ** 0.5).contiguous()
+        b = torch.randn(co).contiguous()
+        h = ctypes.c_void_p()
+        _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
+        f16 = ci % 8 == 0
+        x = torch.randn(B, n, n, ci, device=dev)
+        xin = x.half() if f16 else x
+        no = (n + 2 * (kh // 2) - kh) // s + 1
+        mo = (n + 2 * (kw // 2) - kw) // s + 1
+        ys = -(-co // 4) * 4
+        y = torch.empty(B, no, mo, ys, device=dev, dtype=torch.float16)
+        stamps = torch.zeros(65536 * 8, dtype=torch.int64, device=dev)
+        ptr = stamps.data_ptr()
+
+        def run():
+            _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, xin.data_ptr(), ci, 1 if f16 else 0, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+        for _ in range(3):
+            run()
+        lib.pivlfn_tune(5, ctypes.c_int32(ptr & 0xFFFFFFFF).value)
+        lib.pivlfn_tune(6, ctypes.c_int32((ptr >> 32) & 0xFFFFFFFF).value)
+        run()
+        torch.cuda.synchronize()
+        lib.pivlfn_tune(5, 0)
+        lib.pivlfn_tune(6, 0)
+        t = stamps.view(-1, 8).cpu().numpy()
+        t = t[t[:, 6] > 0]
+        names = ["commit+wait", "barrier1", "load issue", "tap loop", "barrier2", "epilogue", "whole"]
+        tot = t[:, 6].mean()
+        print(f"{name}: {len(t)} workgroups, ticks per workgroup (mean): " +
+              "  ".join(f"{nm} {t[:, i].mean():.0f} ({100 * t[:, i].mean() / tot:.0f}%)" for i, nm in enumerate(names)))
+        span = (t[:, 7] + t[:, 6]).max() - t[:, 7].min()
+        print(f"    kernel span {span} ticks; per-workgroup whole min {t[:, 6].min()} max {t[:, 6].max()}")
+        lib.pivlfn_conv_destroy(h)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv"])
+    ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv", "conv_stamps"])
     ap.add_argument("--filter", default="")
     ap.add_argument("--tune3", type=int, default=0, help="ablation mask of the fp16 conv kernel (pivlfn_tune(3, mask))")
     ap.add_argument("--batch", type=int, default=1)
@@ -165,4 +211,4 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="1,2,0")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
     a = ap.parse_args()
-    {"warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv}[a.what](a)
+    {"conv_stamps": bench_conv_stamps, "warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv}[a.what](a)
