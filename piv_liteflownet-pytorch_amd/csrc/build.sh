@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=../pivlfn/libpivlfn.so
 OBJ=../../build/obj
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $PIVLFN_EXTRA_FLAGS"   # PIVLFN_EXTRA_FLAGS=-DPIVLFN_STAMPS: instrumented build for tools/bench_ops.py conv_stamps
 pids=()
 for f in conv_mfma conv_f16 conv_head warp_corr corr_bwd ops net api; do
   if [ ! -f "$OBJ/$f.o" ] || [ "$f.hip" -nt "$OBJ/$f.o" ] || [ common.h -nt "$OBJ/$f.o" ] || [ ../../include/pivlfn.h -nt "$OBJ/$f.o" ]; then

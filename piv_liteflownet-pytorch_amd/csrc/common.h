@@ -98,6 +98,8 @@ struct ConvParams {
     float *scratch;
     size_t scratch_floats;
     int ksplit;         // number of K shares (set by the launcher; 0/1 = no split)
+    unsigned long long *stamps;   // tools only: per-workgroup phase times (s_memtime ticks), 8 per workgroup; nullptr in production
+    int dbg;            // tools only (-DPIVLFN_STAMPS builds): ablation mask, 1 no MFMAs, 2 no global loads, 4 no epilogue stores
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);

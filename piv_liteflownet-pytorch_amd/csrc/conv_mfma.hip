@@ -226,8 +226,14 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
     const float *sp = p.seg[seg].ptr;
     int scl = p.seg[seg].cload, sst = p.seg[seg].stride;
 
+#ifdef PIVLFN_STAMPS
+#define CONV2_ABL(BIT) (p.dbg & (BIT))
+#else
+#define CONV2_ABL(BIT) false
+#endif
 #define CONV2_LOAD(CH)                                                                            \
     do {                                                                                          \
+        if (CONV2_ABL(2)) break;                                                                  \
         const int qoff_ = (scl - c0 <= 4) ? 0 : q4;      /* 4-channel tail: both quads fetch the same 16 bytes */ \
         _Pragma("unroll") for (int i = 0; i < PMAX; ++i) {                                        \
             f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                       \
@@ -242,6 +248,23 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
     // K loop.  A source whose channel count is 4 (mod 8) ends in a half chunk; the packer only allows that for the LAST
     // source, so the tail is peeled: the hot loop below stays branch-free, and the tail contracts its 4 channels with two
     // MFMAs per tap (k = {j, 2+j}; staged as [c0 c1 c2 c3 | c2 c3 0 0] so both lane halves read their pair at j = 0, 1).
+    // phase stamps (tools/bench_ops.py conv_stamps --tune3 -1; only in a -DPIVLFN_STAMPS build: the accumulators cost
+    // registers the shipped <2,4> and <2,2> tiles do not have)
+#ifdef PIVLFN_STAMPS
+    const bool stamp = p.stamps != nullptr && wave == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    unsigned long long tk = 0, d_commit = 0, d_bar1 = 0, d_issue = 0, d_taps = 0, d_bar2 = 0, t_begin = 0;
+#define STAMP(ACC)                                                                                \
+    do {                                                                                          \
+        if (stamp) {                                                                              \
+            const unsigned long long now_ = __builtin_readcyclecounter();                         \
+            ACC += now_ - tk;                                                                     \
+            tk = now_;                                                                            \
+        }                                                                                         \
+    } while (0)
+    if (stamp) t_begin = tk = __builtin_readcyclecounter();
+#else
+#define STAMP(ACC) do { } while (0)
+#endif
     if (kc0 < kend) CONV2_LOAD(kc0);
     for (int chunk = kc0; chunk < kc1; ++chunk) {
         // registers -> LDS (waits for the loads of this chunk)
@@ -251,7 +274,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
 #pragma unroll
         for (int i = 0; i < WMAX; ++i)
             if (woff[i] >= 0) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+        STAMP(d_commit);
         __syncthreads();
+        STAMP(d_bar1);
         // advance to the next chunk's source and put its loads in flight
         if (chunk + 1 < kend) {
             c0 += 8;
@@ -262,8 +287,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
             }
             CONV2_LOAD(chunk + 1);
         }
+        STAMP(d_issue);
         int tap = 0;
-        for (int ky = 0; ky < p.KH; ++ky) {
+        for (int ky = 0; ky < (CONV2_ABL(1) ? 0 : p.KH); ++ky) {
             for (int kx = 0; kx < p.KW; ++kx, ++tap) {
                 const int toff = (ky * PW + kx) * PIXP;
                 f32x4 a[MT], bq[NT];
@@ -281,8 +307,14 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[n][j], a[m][j], acc[m][n], 0, 0, 0);   // A = channels, B = pixels
             }
         }
+        STAMP(d_taps);
         __syncthreads();       // all waves done with this chunk's LDS image before it is overwritten
+        STAMP(d_bar2);
     }
+#ifdef PIVLFN_STAMPS
+    unsigned long long t_loop_end = 0;
+    if (stamp) t_loop_end = __builtin_readcyclecounter();
+#endif
     if (has_tail) {
 #pragma unroll
         for (int i = 0; i < PMAX; ++i)
@@ -351,6 +383,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
                 for (int g = 0; g < 4; ++g) {
                     const int ch = n0 + n * 32 + 8 * g + 4 * hh;
                     if (!pix_ok || (!interior && ch >= p.cout_store)) continue;
+                    if (CONV2_ABL(4) && acc[m][n][0] != 12345.f) continue;
                     f32x4 v = {acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
                     v += *reinterpret_cast<const f32x4 *>(p.bias + ch);
                     if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + ch);
@@ -362,6 +395,17 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
             }
         }
     }
+#ifdef PIVLFN_STAMPS
+    if (stamp && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 8;
+        o[0] = d_commit; o[1] = d_bar1; o[2] = d_issue; o[3] = d_taps; o[4] = d_bar2;
+        o[5] = t_end - t_loop_end;       // (tail chunk +) epilogue
+        o[6] = t_end - t_begin;
+        o[7] = t_begin;
+    }
+#endif
+#undef STAMP
 }
 
 // Second pass of a split-K layer: out = act(bias + residual + sum_z scratch[z]), z ascending (deterministic), 4 channels per thread.
@@ -553,6 +597,8 @@ static int launch_conv_k1(const ConvParams &p, hipStream_t st)
 static int launch_conv2(const ConvParams &p_in, hipStream_t st)
 {
     ConvParams p = p_in;
+    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)g_knob[6] << 32) | (unsigned)g_knob[5]);   // tools only
+    p.dbg = g_knob[7];
     const int taps = p.KH * p.KW;
     // Split-K when one image has too few tiles for the chip and the K loop is long enough to be worth sharing.  Decided from
     // the per-image count of canonical (4 rows x 32 px x 32 channels) tiles only -- never from the batch size or from the tile

@@ -109,6 +109,7 @@ def bench_conv(args):
     import ctypes
     lib = _lib.load()
     lib.pivlfn_tune(3, args.tune3)
+    lib.pivlfn_tune(7, args.tune7)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     variants = [int(v) for v in args.variants.split(",")]
@@ -170,18 +171,22 @@ def bench_conv_stamps(args):
         b = torch.randn(co).contiguous()
         h = ctypes.c_void_p()
         _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
-        f16 = ci % 8 == 0
+        fp32 = args.tune3 == -1                     # --tune3 -1: stamp the fp32 kernel instead
+        f16 = ci % 8 == 0 and not fp32
         x = torch.randn(B, n, n, ci, device=dev)
         xin = x.half() if f16 else x
         no = (n + 2 * (kh // 2) - kh) // s + 1
         mo = (n + 2 * (kw // 2) - kw) // s + 1
         ys = -(-co // 4) * 4
-        y = torch.empty(B, no, mo, ys, device=dev, dtype=torch.float16)
+        y = torch.empty(B, no, mo, ys, device=dev, dtype=torch.float32 if fp32 else torch.float16)
         stamps = torch.zeros(65536 * 8, dtype=torch.int64, device=dev)
         ptr = stamps.data_ptr()
 
         def run():
-            _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, xin.data_ptr(), ci, 1 if f16 else 0, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+            if fp32:
+                _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+            else:
+                _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, xin.data_ptr(), ci, 1 if f16 else 0, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
         for _ in range(3):
             run()
         lib.pivlfn_tune(5, ctypes.c_int32(ptr & 0xFFFFFFFF).value)
@@ -206,6 +211,7 @@ if __name__ == "__main__":
     ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv", "conv_stamps"])
     ap.add_argument("--filter", default="")
     ap.add_argument("--tune3", type=int, default=0, help="ablation mask of the fp16 conv kernel (pivlfn_tune(3, mask))")
+    ap.add_argument("--tune7", type=int, default=0, help="ablation mask of the fp32 conv kernel in a -DPIVLFN_STAMPS build (pivlfn_tune(7, mask))")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
     ap.add_argument("--variants", default="1,2,0")
