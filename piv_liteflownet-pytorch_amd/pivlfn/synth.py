@@ -208,3 +208,57 @@ def particle_batch(B: int, H: int, W: int, seed: int = 1234):
         i1, i2, _ = particle_pair(H, W, seed + b)
         a.append(to_input(i1)); c.append(to_input(i2))
     return np.stack(a), np.stack(c)
+
+
+# ---- frame sequences generated on the device (BASELINE config #4: a long synthetic PIV sequence, sharded over ranks) ----------
+class ParticleSequence:
+    """A deterministic particle-image SEQUENCE rendered with torch ops on any device: the same particle model as
+    `particle_pair` (density, diameter, intensity), particles advected frame to frame by the Lamb-Oseen + uniform-shift field,
+    wrapped around a margin so the seeding density stays constant.  Frame k is a pure function of (seed, k): every rank can
+    render exactly the frames of its shard (plus the halo frame) and all ranks agree on them.
+
+    frames(k0, k1) -> uint8 [k1-k0, H, W].  Rendering is a scatter-add of each particle's 9x9 Gaussian footprint."""
+
+    def __init__(self, H: int, W: int, seed: int = 1234, density: float = 0.05, peak: float = 4.0,
+                 shift: Tuple[float, float] = (1.5, -0.75), device="cpu"):
+        import torch
+        self.H, self.W, self.peak, self.shift, self.m = H, W, peak, shift, 16
+        self.device = torch.device(device)
+        g = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, 0x51ED270B]))
+        n = int(np.floor(density * (H + 2 * self.m) * (W + 2 * self.m)))
+        self._x0 = g.random(n) * (W + 2 * self.m) - self.m
+        self._y0 = g.random(n) * (H + 2 * self.m) - self.m
+        self.z = torch.from_numpy(g.random(n) - 0.5).to(self.device, torch.float32)
+        self.d = torch.from_numpy(1.5 + g.random(n)).to(self.device, torch.float32)
+        self._k = 0
+        self._x, self._y = self._x0.copy(), self._y0.copy()
+
+    def _positions(self, k: int):
+        if k < self._k:
+            self._k, self._x, self._y = 0, self._x0.copy(), self._y0.copy()
+        W2, H2, m = self.W + 2 * self.m, self.H + 2 * self.m, self.m
+        while self._k < k:                                 # float64 on the host: 52 k particles per step, negligible
+            u, v = displacement_field(self._x, self._y, self.H, self.W, self.peak, self.shift)
+            self._x = (self._x + u + m) % W2 - m
+            self._y = (self._y + v + m) % H2 - m
+            self._k += 1
+        return self._x, self._y
+
+    def frames(self, k0: int, k1: int):
+        import torch
+        out = torch.empty(k1 - k0, self.H, self.W, dtype=torch.uint8, device=self.device)
+        rad = 4
+        oy, ox = torch.meshgrid(torch.arange(-rad, rad + 2, device=self.device), torch.arange(-rad, rad + 2, device=self.device), indexing="ij")
+        oy, ox = oy.reshape(1, -1), ox.reshape(1, -1)
+        inten = 240.0 * torch.exp(-(self.z ** 2))
+        for k in range(k0, k1):
+            xs, ys = self._positions(k)
+            x = torch.from_numpy(xs).to(self.device, torch.float32)[:, None]
+            y = torch.from_numpy(ys).to(self.device, torch.float32)[:, None]
+            ix, iy = torch.floor(x).long() + ox, torch.floor(y).long() + oy
+            val = inten[:, None] * torch.exp(-((ix - x) ** 2 + (iy - y) ** 2) / ((0.5 * self.d[:, None]) ** 2))
+            ok = (ix >= 0) & (ix < self.W) & (iy >= 0) & (iy < self.H)
+            img = torch.zeros(self.H * self.W, dtype=torch.float32, device=self.device)
+            img.index_add_(0, (iy * self.W + ix)[ok], val[ok])
+            out[k - k0] = img.view(self.H, self.W).clamp_(0, 255).to(torch.uint8)
+        return out

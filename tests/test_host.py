@@ -88,3 +88,21 @@ def test_golden_inputs_are_reproducible_from_seeds(gold):
     a, b, _ = synth.particle_pair(64, 64, seed)
     assert np.array_equal(a, gold["e2e_cases"]["piv_1x64x64_img1"][0])
     assert np.array_equal(b, gold["e2e_cases"]["piv_1x64x64_img2"][0])
+
+
+def test_particle_sequence_is_a_pure_function_of_seed_and_frame_index():
+    """BASELINE config #4's synthetic sequence: every rank renders only its shard's frames, so frame k must not depend on
+    which frames were rendered before it; consecutive frames must differ by the advection (a pair has a flow to find)."""
+    import torch
+    from pivlfn import synth
+    a = synth.ParticleSequence(64, 96, seed=5).frames(0, 4)
+    b = synth.ParticleSequence(64, 96, seed=5).frames(2, 4)
+    assert a.dtype == torch.uint8 and a.shape == (4, 64, 96)
+    assert torch.equal(a[2:], b)
+    s = synth.ParticleSequence(64, 96, seed=5)
+    later = s.frames(3, 4)
+    earlier = s.frames(1, 2)                                   # going backwards restarts the advection
+    assert torch.equal(later[0], a[3]) and torch.equal(earlier[0], a[1])
+    assert not torch.equal(a[0], a[1])
+    assert 10.0 < a.float().mean().item() < 80.0               # same seeding density / intensity model as particle_pair
+    assert not torch.equal(synth.ParticleSequence(64, 96, seed=6).frames(0, 1), a[:1])
