@@ -234,7 +234,10 @@ def main():
             "roofline": roof,
             "whole_net": {"conv_tflops": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
                           "fp32_mfma_peak_tflops": 157.3,
-                          "compute_frac": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None},
+                          "compute_frac": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None,
+                          # layer-boundary bytes of the reference's graph (in + out + weights of every conv, fp32)
+                          "layer_boundary_gb_per_pair": 16.57 if (args.model == 'piv' and S == 1024) else None,
+                          "hbm_frac_of_8tbs": round(value / world * 16.57 / 8000.0, 4) if (args.model == 'piv' and S == 1024) else None},
         }
         if world == 1 and args.model == "piv" and S == 1024:
             out["roofline_batch8"] = l3_throughput_regime(dev)
