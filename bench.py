@@ -222,8 +222,9 @@ def main():
                              "stream the kernel runs on; event_record_pair_us = plain hipEventRecord pair around the same launch "
                              "(adds the marker packets' own cost); rocprofv3 average for the same kernel: profiles/"}
         out = {
-            "metric": (f"PIV image-pairs/s at {S}x{S} fp32" if args.precision == "fp32" else
-                       f"PIV image-pairs/s at {S}x{S}, fp16-multiplicand conv mode (BASELINE config #5 variant; not the fp32 headline)"),
+            "metric": (("PIV" if args.model == "piv" else "LiteFlowNet (Hui weights layout)") +
+                       (f" image-pairs/s at {S}x{S} fp32" if args.precision == "fp32" else
+                        f" image-pairs/s at {S}x{S}, fp16-multiplicand conv mode (BASELINE config #5 variant; not the fp32 headline)")),
             "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16 multiplicands, f32 accumulate", "data": "synthetic",
