@@ -196,192 +196,13 @@ __global__ __launch_bounds__(256) void warp_corr_kernel(const WcParams p)
 }
 
 
-// ---- channels-last kernel (the one pivlfn_forward launches) ---------------------------------------------------------
-// v2 structure, built for memory-level parallelism (a tile is ~200 KB of gathers behind a dependent flow read):
-//   phase 0  every thread issues its share of the f1 tile loads (independent of everything else);
-//   phase A  196 threads read the flow at their position and write the 4 bilinear taps (pixel index or -1, weight)
-//            into an LDS tap table -- ONE dependent round trip per tile instead of one per gathered vector;
-//   phase B  all threads gather (position, 16-byte channel quad) items: tap table from LDS, four unconditional
-//            16-byte loads (index clamped, value masked afterwards), unrolled by UNR so >= 16 loads per thread are in
-//            flight; blended vectors go to LDS;
-//   phase C  lane = output pixel, wave = displacement group, operands streamed with ds_read_b128 (as v1);
-//   NW waves per workgroup (8 -> two waves per SIMD, so VALU issue and LDS latency overlap).
-template <int CC, int NW, bool HASFLOW>
-__global__ __launch_bounds__(NW * 64) void warp_corr_nhwc_kernel(const WcParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT = NW * 64;
-    constexpr int PP = CC + 4;
-    constexpr int Q = CC / 4;
-    constexpr int ND = (49 + NW - 1) / NW;   // displacements per thread
-    float *f2w = smem;                       // [NPOS][PP]
-    float *f1t = f2w + NPOS * PP;            // [64][PP]
-    int *tapo = reinterpret_cast<int *>(f1t + 64 * PP);   // [4][NPOS]
-    float *tapw = reinterpret_cast<float *>(tapo + 4 * NPOS);
-
-    const int tiles_x = (p.Wo + TO - 1) / TO, tiles_y = (p.Ho + TO - 1) / TO;
-    const int nblk = tiles_x * tiles_y * p.B;
-    int bid = xcd_remap(blockIdx.x, nblk);
-    const int tx = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int ox0 = tx * TO, oy0 = ty * TO;
-    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
-    const int ppx = lane & 7, ppy = lane >> 3;
-    const size_t img = (size_t)p.H * p.W;
-    const float *f1img = p.f1 + (size_t)b * img * p.C;
-    const float *f2img = p.f2 + (size_t)b * img * p.C;
-
-    // phase A: tap table (shared by all channel chunks)
-    if (tid < NPOS) {
-        const int iy = (oy0 + tid / TP - 3) * p.s, ix = (ox0 + tid % TP - 3) * p.s;
-        Taps t;
-        t.o00 = t.o01 = t.o10 = t.o11 = -1;
-        t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            if (HASFLOW) {
-                const float2 uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)iy * p.W + ix) * 4);
-                t = make_taps((float)ix + uv.x * p.scale, (float)iy + uv.y * p.scale, p.H, p.W);
-            } else {
-                t.o00 = iy * p.W + ix;
-                t.w00 = 1.f;
-            }
-        }
-        tapo[0 * NPOS + tid] = t.o00; tapo[1 * NPOS + tid] = t.o01; tapo[2 * NPOS + tid] = t.o10; tapo[3 * NPOS + tid] = t.o11;
-        tapw[0 * NPOS + tid] = t.w00; tapw[1 * NPOS + tid] = t.w01; tapw[2 * NPOS + tid] = t.w10; tapw[3 * NPOS + tid] = t.w11;
-    }
-
-    float acc[ND];
-#pragma unroll
-    for (int k = 0; k < ND; ++k) acc[k] = 0.f;
-    constexpr int F1_PER = (64 * Q + NT - 1) / NT;
-    constexpr int NITEM = NPOS * Q;
-    constexpr int UNR = HASFLOW ? 4 : 8;
-
-    for (int c0 = 0; c0 < p.C; c0 += CC) {
-        // phase 0: f1 tile -> registers (stored to LDS after the barrier below)
-        f32x4 f1r[F1_PER];
-#pragma unroll
-        for (int i = 0; i < F1_PER; ++i) {
-            const int idx = tid + i * NT;
-            const int pp = idx / Q, q = idx - pp * Q;
-            const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < 64 * Q && oy < p.Ho && ox < p.Wo)
-                v = *reinterpret_cast<const f32x4 *>(f1img + ((size_t)(oy * p.s) * p.W + ox * p.s) * p.C + c0 + 4 * q);
-            f1r[i] = v;
-        }
-        __syncthreads();        // tap table visible (first chunk) / previous chunk's compute finished (later chunks)
-        // phase B: gather + blend
-        const float *f2c = f2img + c0;
-        for (int base = 0; base < NITEM; base += NT * UNR) {
-            f32x4 x[UNR][HASFLOW ? 4 : 1];
-            float w[UNR][HASFLOW ? 4 : 1];
-            int o[UNR][HASFLOW ? 4 : 1];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                int idx = base + u * NT + tid;
-                idx = idx < NITEM ? idx : NITEM - 1;
-                const int pos = idx / Q, q = idx - pos * Q;
-#pragma unroll
-                for (int k = 0; k < (HASFLOW ? 4 : 1); ++k) {
-                    o[u][k] = tapo[k * NPOS + pos];
-                    w[u][k] = tapw[k * NPOS + pos];
-                    const int oc = o[u][k] < 0 ? 0 : o[u][k];
-                    x[u][k] = *reinterpret_cast<const f32x4 *>(f2c + (size_t)oc * p.C + 4 * q);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int idx = base + u * NT + tid;
-                if (idx < NITEM) {
-                    const int pos = idx / Q, q = idx - pos * Q;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < (HASFLOW ? 4 : 1); ++k)
-                        if (o[u][k] >= 0) v += w[u][k] * x[u][k];
-                    *reinterpret_cast<f32x4 *>(f2w + pos * PP + 4 * q) = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < F1_PER; ++i) {
-            const int idx = tid + i * NT;
-            if (idx < 64 * Q) {
-                const int pp = idx / Q, q = idx - pp * Q;
-                *reinterpret_cast<f32x4 *>(f1t + pp * PP + 4 * q) = f1r[i];
-            }
-        }
-        __syncthreads();
-
-        // phase C
-        f32x4 a[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) a[q] = *reinterpret_cast<const f32x4 *>(f1t + lane * PP + 4 * q);
-#pragma unroll
-        for (int k = 0; k < ND; ++k) {
-            const int d = grp + NW * k;
-            if (d < 49) {
-                const int dy = d / 7, dx = d - dy * 7;
-                const float *src = f2w + ((ppy + dy) * TP + ppx + dx) * PP;
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int q = 0; q < Q; q += 2) {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + 4 * q);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(src + 4 * q + 4);
-                    s0 = fmaf(a[q][0], v0[0], s0); s0 = fmaf(a[q][1], v0[1], s0);
-                    s0 = fmaf(a[q][2], v0[2], s0); s0 = fmaf(a[q][3], v0[3], s0);
-                    s1 = fmaf(a[q + 1][0], v1[0], s1); s1 = fmaf(a[q + 1][1], v1[1], s1);
-                    s1 = fmaf(a[q + 1][2], v1[2], s1); s1 = fmaf(a[q + 1][3], v1[3], s1);
-                }
-                acc[k] += s0 + s1;
-            }
-        }
-    }
-
-    __syncthreads();
-    float *ost = smem;                       // [64][56], exact zeros in lanes 49..55
-    const float cf = (float)p.C;
-#pragma unroll
-    for (int k = 0; k < ND; ++k) {
-        const int d = grp + NW * k;
-        if (d < 49) {
-            float v = acc[k] / cf;
-            if (p.leaky) v = lrelu01(v);
-            ost[lane * OUTC + d] = v;
-        }
-    }
-    if (grp == 0) {
-#pragma unroll
-        for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 64 * (OUTC / 4); idx += NT) {
-        const int pp = idx / (OUTC / 4), q = idx - pp * (OUTC / 4);
-        const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
-        if (oy < p.Ho && ox < p.Wo)
-            *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) =
-                *reinterpret_cast<const f32x4 *>(ost + pp * OUTC + 4 * q);
-    }
-}
-
-template <int CC, int NW, bool HASFLOW>
-static int launch_wc2(const WcParams &p, hipStream_t st)
-{
-    const size_t lds = ((size_t)(NPOS + 64) * (CC + 4) + 8 * NPOS) * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_nhwc_kernel<CC, NW, HASFLOW>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
-    hipLaunchKernelGGL((warp_corr_nhwc_kernel<CC, NW, HASFLOW>), dim3(nblk), dim3(NW * 64), lds, st, p);
-    PIV_CHECK_HIP(hipGetLastError());
-    return PIVLFN_OK;
-}
-
+// ---- channels-last kernels (the ones pivlfn_forward launches) -----------------------------------------------------
+// Common structure, built for memory-level parallelism (a tile is ~200 KB of gathers behind a dependent flow read):
+//   phase A  196 threads read the flow at their position and write the 4 bilinear taps (byte offset or out-of-range sentinel,
+//            weight) into an LDS tap table -- ONE dependent round trip per tile instead of one per gathered vector;
+//   phase B  all threads gather (position, 16-byte channel quad) items through buffer loads, blended vectors go to LDS;
+//   phase C  dot products from LDS with ds_read_b128; phase D  the 56-lane output leaves as whole 16-byte lanes.
+// (An earlier generation -- whole-C vectors, 4 or 8 waves, clamped-index gathers -- was 2-3x slower and is gone.)
 
 // ---- v3: 32-channel chunks, double-buffered LDS, gathers of chunk k+1 in flight while chunk k is consumed -------------
 // 512 threads (two waves per SIMD).  All gathers are buffer loads through a per-image descriptor: one 32-bit byte
@@ -912,13 +733,7 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
             return flow ? launch_wc4<true>(p, st) : launch_wc4<false>(p, st);
         if (variant == 4) return flow ? launch_wc3<true, false>(p, st) : launch_wc3<false, false>(p, st);     // A/B: one pixel per lane
         if (variant == 0 || variant == 5 || variant == 6) return flow ? launch_wc3<true, true>(p, st) : launch_wc3<false, true>(p, st);
-        if (variant == 2) {                       // v2 with 4 waves
-            if (C % 64 == 0) return flow ? launch_wc2<64, 4, true>(p, st) : launch_wc2<64, 4, false>(p, st);
-            return flow ? launch_wc2<32, 4, true>(p, st) : launch_wc2<32, 4, false>(p, st);
-        }
-        // variant 3: v2 with 8 waves
-        if (C % 64 == 0) return flow ? launch_wc2<64, 8, true>(p, st) : launch_wc2<64, 8, false>(p, st);
-        return flow ? launch_wc2<32, 8, true>(p, st) : launch_wc2<32, 8, false>(p, st);
+        PIV_REQUIRE(false, "warp_corr: unknown kernel variant %d", variant);
     }
     if (C % 64 == 0) return launch_wc<64, false>(p, st);
     return launch_wc<32, false>(p, st);   // any C: the last chunk is zero-filled past C

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B micro-benchmarks of single kernels at the shapes of the 1024x1024 PIV forward (one process, interleaved rounds).
 
-  python tools/bench_ops.py warp_corr [--batch 1] [--variants 1,2,0]
+  python tools/bench_ops.py warp_corr [--batch 1] [--variants 1,4,5,0]   (1 first generation, 4 v3 one pixel per lane, 5 v4, 0 shipped policy)
 Times N back-to-back launches between two events on the current stream (so each figure includes one ~1.5 us
 kernel boundary) and checks that all variants agree.
 """
@@ -214,7 +214,7 @@ if __name__ == "__main__":
     ap.add_argument("--tune7", type=int, default=0, help="ablation mask of the fp32 conv kernel in a -DPIVLFN_STAMPS build (pivlfn_tune(7, mask))")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
-    ap.add_argument("--variants", default="1,2,0")
+    ap.add_argument("--variants", default="1,4,0")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
     a = ap.parse_args()
     {"conv_stamps": bench_conv_stamps, "warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv}[a.what](a)
