@@ -154,6 +154,16 @@ def test_forward_is_graph_capturable(nets, dev):
     assert torch.equal(swapped, net(torch.from_numpy(b).to(dev), torch.from_numpy(a).to(dev)))
 
 
+def test_degenerate_sizes_stay_finite(nets, dev):
+    """Sizes for which the reference itself returns NaN (a level-6 map one pixel wide: tests/test_oracle.py): finite here, and
+    the right shape."""
+    for H, W in [(32, 32), (20, 28), (64, 32), (1, 1)]:
+        g = torch.Generator().manual_seed(H * 100 + W)
+        i1, i2 = torch.rand(1, 3, H, W, generator=g).to(dev), torch.rand(1, 3, H, W, generator=g).to(dev)
+        out = pivlfn.estimate(nets["piv"], i1, i2, tensor=True)
+        assert out.shape == (1, 2, H, W) and torch.isfinite(out).all()
+
+
 def test_reloading_weights_takes_effect(dev):
     net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
     a, b = synth.particle_batch(1, 64, 64, seed=5)

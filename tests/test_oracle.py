@@ -156,3 +156,16 @@ def test_correlation_backward_known_answer():
     w1[0, 0, 3, 4] = f2[0, 0, 4, 2]
     w2[0, 0, 4, 2] = f1[0, 0, 3, 4]
     assert np.array_equal(g1, w1) and np.array_equal(g2, w2)
+
+
+def test_reference_arithmetic_is_nan_when_a_level_collapses_to_one_pixel():
+    """Documented difference: for inputs whose padded size is 32 in a dimension the level-6 maps are one
+    pixel wide and the reference's backwarp divides the flow by (W - 1) / 2 = 0 (src/models.py:28-30): its output is NaN.  The
+    oracle restates that arithmetic, so it is NaN too; the HIP path works in pixel units and returns finite flow
+    (tests/test_gpu_net.py::test_degenerate_sizes_stay_finite)."""
+    wts = synth.generate_weights("piv", 0)
+    net = orc.make_net("piv", wts, corr="c")
+    g = torch.Generator().manual_seed(1)
+    i1, i2 = torch.rand(1, 3, 32, 64, generator=g), torch.rand(1, 3, 32, 64, generator=g)
+    out = orc.estimate(net, i1, i2, tensor=True)
+    assert out.shape == (1, 2, 32, 64) and not torch.isfinite(out).all()
