@@ -13,7 +13,10 @@ namespace pivlfn {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int K>
+// WLDS: weights staged in LDS and read as broadcast ds_reads instead of through the scalar cache.  On a grid of a few
+// workgroups (the coarse levels) the K*K*8 dependent s_load round trips are the whole kernel (22 us for 32x32 pixels); with many
+// waves per CU they hide behind each other and the scalar path is the better one (it keeps LDS bandwidth for the patch).
+template <int K, bool WLDS>
 __global__ __launch_bounds__(256) void conv_head_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         float b0, float b1, const float *__restrict__ res4,
                                                         float *__restrict__ out4, int B, int H, int W)
@@ -28,6 +31,9 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float *__restrict_
     const int b = bid / tiles_y;
     const int tid = threadIdx.x;
     const float *xb = x + (size_t)b * H * W * 32;
+    float *wl = smem + NPIX * 32;
+    if (WLDS)
+        for (int i = tid; i < K * K * 64; i += 256) wl[i] = w[i];
 
     for (int idx = tid; idx < NPIX * 8; idx += 256) {
         const int pix = idx >> 3, q = idx & 7;
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float *__restrict_
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
-        const float *wr = w + ky * K * 64;      // [kx][quad][out][4]
+        const float *wr = (WLDS ? wl : w) + ky * K * 64;      // [kx][quad][out][4]
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
             const int c = lx + kx;
@@ -76,15 +82,22 @@ static int launch_head_t(const float *x, const float *w, float b0, float b1, con
                          hipStream_t st)
 {
     constexpr int PW = 16 + K - 1;
-    const size_t lds = (size_t)PW * PW * 32 * sizeof(float);
+    const size_t lds = ((size_t)PW * PW * 32 + K * K * 64) * sizeof(float);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_head_kernel<K>),
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_head_kernel<K, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_head_kernel<K, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const int nblk = cdiv(W, 16) * cdiv(H, 16) * B;
-    hipLaunchKernelGGL((conv_head_kernel<K>), dim3(nblk), dim3(256), lds, st, x, w, b0, b1, res4, out4, B, H, W);
+    // (per image, so that a pair's flow never depends on its batch mates -- the two variants differ in nothing but the weight path,
+    //  and produce the same bits, but the rule costs nothing)
+    if (cdiv(W, 16) * cdiv(H, 16) <= 512 && !(g_knob[1] & 1024))
+        hipLaunchKernelGGL((conv_head_kernel<K, true>), dim3(nblk), dim3(256), lds, st, x, w, b0, b1, res4, out4, B, H, W);
+    else
+        hipLaunchKernelGGL((conv_head_kernel<K, false>), dim3(nblk), dim3(256), lds, st, x, w, b0, b1, res4, out4, B, H, W);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
