@@ -130,17 +130,17 @@ def bench_conv(args):
         outs = {}
         xh = None
         for v in variants:
-            # variants >= 1000 select the fp16-multiplicand kernel: even = fp32 in / fp32 out, odd = fp16 in / fp16 out;
-            # (v - 1000) >> 1 goes to the tuning knob (pivlfn_tune(1, .)): 1000/1001 shipped policy, 1128/1129 = knob 64
-            f16io = v >= 1000 and (v & 1) == 1
+            # variants >= 100000 select the fp16-multiplicand kernel: even = fp32 in / fp32 out, odd = fp16 in / fp16 out;
+            # (v - 100000) >> 1 goes to the tuning knob (pivlfn_tune(1, .)): 100000/100001 shipped policy, 100128/100129 = knob 64
+            f16io = v >= 100000 and (v & 1) == 1
             y = torch.empty(B, no, mo, ys, device=dev, dtype=torch.float16 if f16io else torch.float32)
             outs[v] = y
             if f16io and xh is None and ci % 8 == 0:
                 xh = x.half()
 
             def fn(v=v, y=y, f16io=f16io):
-                lib.pivlfn_tune(1, (v - 1000) >> 1 if v >= 1000 else v)
-                if v >= 1000:
+                lib.pivlfn_tune(1, (v - 100000) >> 1 if v >= 100000 else v)
+                if v >= 100000:
                     if f16io and ci % 8 == 0:
                         _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, xh.data_ptr(), ci, 1, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
                     else:
