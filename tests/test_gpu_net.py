@@ -1,4 +1,6 @@
 """GPU: pivlfn_forward (the whole level pipeline as HIP kernels) against golden flows of the reference and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -216,6 +218,33 @@ def test_run_py_end_to_end(tmp_path, dev):
         i2 = torch.from_numpy(synth.to_input(frames[k + 1]))[None].to(dev)
         want = pivlfn.estimate(net, i1, i2, tensor=False)
         assert got.shape == (64, 96, 2) and np.array_equal(got, want)
+
+
+def test_run_py_version2_pair_folder(tmp_path, dev):
+    """run.py -p (pair folder, `*_img1/_img2` naming, src/datasets.py:447-455) with --version 2 --model hui: the v2 Hui
+    network returns quarter-resolution flow, which estimate() resizes to the input size; .flo equals estimate() bit for bit."""
+    import PIL.Image
+    import run as runpy
+    from pivlfn.flo import read_flow
+    d = tmp_path / "left"
+    d.mkdir()
+    pairs = []
+    for k in range(2):
+        a, b, _ = synth.particle_pair(96, 64, 500 + k)
+        PIL.Image.fromarray(a).save(str(d / f"shot{k}_img1.png"))
+        PIL.Image.fromarray(b).save(str(d / f"shot{k}_img2.png"))
+        pairs.append((a, b))
+    out = tmp_path / "out"
+    n = runpy.main(["--model", "hui", "-v", "2", "-p", "-i", str(d), "-o", str(out), "--batch", "2"])
+    assert n == 2
+    # a folder called left/right goes under flow/left of its parent's name (run.py:241-249)
+    flodir = out / "hui2-synthetic" / os.path.basename(str(tmp_path)) / "flow" / "left"
+    assert (out / "hui2-synthetic" / os.path.basename(str(tmp_path)) / "args_left.txt").exists()
+    net = pivlfn.Network(model="hui", params=synth.generate_weights("hui2", 0), version=2).to(dev).eval()
+    for k, (a, b) in enumerate(pairs):
+        got = read_flow(str(flodir / f"shot{k}_out.flo"))
+        want = pivlfn.estimate(net, torch.from_numpy(synth.to_input(a))[None].to(dev), torch.from_numpy(synth.to_input(b))[None].to(dev), tensor=False)
+        assert got.shape == (96, 64, 2) and np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("tag", ["piv2_1x64x64", "piv2_2x96x160", "hui2_1x64x96"])
