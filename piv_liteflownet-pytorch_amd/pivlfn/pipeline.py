@@ -4,7 +4,8 @@ The reference reads, converts, uploads, infers, downloads and writes one pair at
 (`for images, fname in tqdm(dataset)`: run.py:155-166).  Here the three stages overlap:
 
   loader thread : decode each frame ONCE (sequence mode reuses frame i+1 of pair i as frame i of pair i+1), as uint8 HWC,
-                  group equal-sized pairs into batches, stage them in pinned host memory          (PairLoader)
+                  on a small pool of decode threads, one batch ahead; group equal-sized pairs into batches, stage them
+                  in pinned host memory                                                              (PairLoader)
   main thread   : H2D of the uint8 batch on a copy stream, uint8 -> fp32 NCHW / 255 on the device (the arithmetic of
                   torchvision's ToTensor that the reference uses, src/datasets.py:452-453), `estimate`
   D2H + writer  : flow -> pinned buffer on the copy stream, an event per batch; the writer threads wait on the event and
@@ -49,10 +50,11 @@ class PairLoader:
     A batch never mixes image sizes.  Decoding runs on a background thread, `depth` batches ahead."""
 
     def __init__(self, dataset, lo: int, hi: int, batch: int, depth: int = 2, pin: bool = False,
-                 reader: Callable[[str], np.ndarray] = read_image_u8):
-        if batch < 1 or depth < 1:
-            raise ValueError("PairLoader: batch and depth must be >= 1")
+                 reader: Callable[[str], np.ndarray] = read_image_u8, workers: int = 4):
+        if batch < 1 or depth < 1 or workers < 1:
+            raise ValueError("PairLoader: batch, depth and workers must be >= 1")
         self.ds, self.lo, self.hi, self.batch, self.pin, self.reader = dataset, lo, hi, batch, pin, reader
+        self.workers = workers                             # decode threads (PIL releases the GIL while it decodes)
         self.decoded = 0                                   # frames actually decoded (tests: sequence mode decodes n+1, not 2n)
         self._q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._stop = threading.Event()
@@ -60,13 +62,6 @@ class PairLoader:
         self._thread.start()
 
     # ---- producer ------------------------------------------------------------------------------------------------
-    def _frame(self, path: str, cache: dict) -> np.ndarray:
-        if path in cache:
-            return cache[path]
-        a = self.reader(path)
-        self.decoded += 1
-        return a
-
     def _emit(self, names: List[str], f1: List[np.ndarray], f2: List[np.ndarray]) -> bool:
         def stack(frames):
             t = torch.from_numpy(np.stack(frames))
@@ -81,27 +76,44 @@ class PairLoader:
         return False
 
     def _produce(self) -> None:
+        from concurrent.futures import ThreadPoolExecutor
         try:
-            names: List[str] = []
-            f1: List[np.ndarray] = []
-            f2: List[np.ndarray] = []
-            cache: dict = {}
-            for i in range(self.lo, self.hi):
-                p1, p2 = self.ds.image_list[i]
-                a = self._frame(p1, cache)
-                b = self._frame(p2, cache)
-                cache = {p2: b}                            # the only frame a following pair can share (src/datasets.py:456-463)
-                if a.shape != b.shape:
-                    raise ValueError(f"pair '{self.ds.name_list[i]}': image sizes differ {a.shape} vs {b.shape}")
-                if names and (len(names) == self.batch or a.shape != f1[0].shape):
-                    if not self._emit(names, f1, f2):
-                        return
-                    names, f1, f2 = [], [], []
-                names.append(self.ds.name_list[i])
-                f1.append(a)
-                f2.append(b)
-            if names and not self._emit(names, f1, f2):
-                return
+            with ThreadPoolExecutor(max_workers=self.workers) as pool:
+                # decode ahead: the distinct frames of the next `batch` pairs are submitted together, each exactly once
+                pending: dict = {}
+
+                def want(path):
+                    if path not in pending:
+                        pending[path] = pool.submit(self.reader, path)
+                        self.decoded += 1
+
+                names: List[str] = []
+                f1: List[np.ndarray] = []
+                f2: List[np.ndarray] = []
+                ahead = self.lo
+                for i in range(self.lo, self.hi):
+                    while ahead < min(self.hi, i + self.batch):
+                        for path in self.ds.image_list[ahead]:
+                            want(path)
+                        ahead += 1
+                    p1, p2 = self.ds.image_list[i]
+                    a, b = pending[p1].result(), pending[p2].result()
+                    # a frame can only be shared with the following pair (src/datasets.py:456-463): drop everything older
+                    nxt = set(self.ds.image_list[i + 1]) if i + 1 < self.hi else set()
+                    for path in (p1, p2):
+                        if path not in nxt:
+                            pending.pop(path, None)
+                    if a.shape != b.shape:
+                        raise ValueError(f"pair '{self.ds.name_list[i]}': image sizes differ {a.shape} vs {b.shape}")
+                    if names and (len(names) == self.batch or a.shape != f1[0].shape):
+                        if not self._emit(names, f1, f2):
+                            return
+                        names, f1, f2 = [], [], []
+                    names.append(self.ds.name_list[i])
+                    f1.append(a)
+                    f2.append(b)
+                if names and not self._emit(names, f1, f2):
+                    return
             self._q.put(None)
         except BaseException as e:                         # noqa: BLE001  -- re-raised on the consumer side
             self._q.put(e)
