@@ -43,7 +43,8 @@ def estimate(net: torch.nn.Module, img1: torch.Tensor, img2: torch.Tensor, tenso
         a = _resize(a, ah, aw)
         b = _resize(b, ah, aw)
     with torch.set_grad_enabled(False):
-        net.eval()
+        if net.training:                # the reference calls net.eval() unconditionally (inference.py:52); it walks every submodule
+            net.eval()
         raw = net(a, b)
     if raw.shape[2:] == (H, W) and sw == 1.0 and sh == 1.0:
         flow = raw                      # same-size bilinear resize is the identity; scale factors are 1

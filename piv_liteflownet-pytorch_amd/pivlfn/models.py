@@ -50,8 +50,15 @@ def backwarp(tensorInput: torch.Tensor, tensorFlow: torch.Tensor) -> torch.Tenso
     return out
 
 
+_PARAM_GEN = [0]      # bumped whenever any parameter object is (re)registered on any holder: invalidates cached parameter lists
+
+
 class _Holder(torch.nn.Module):
     """Parameter container; exists only so that state_dict() has the reference's key names."""
+
+    def register_parameter(self, name, param):
+        _PARAM_GEN[0] += 1
+        return super().register_parameter(name, param)
 
 
 class LiteFlowNet(torch.nn.Module):
@@ -110,8 +117,19 @@ class LiteFlowNet(torch.nn.Module):
 
     # -- native handle ---------------------------------------------------------------------------------
     def _key(self):
-        ps = list(self.parameters())
+        # the parameter list is cached: walking the 250-module tree on every forward costs 2 ms of host time, which is what
+        # a small or fp16-mode forward takes on the GPU (load_state_dict / .to() change data in place or swap .data: both
+        # show up in _version / data_ptr, and _apply() drops the cache)
+        ps = self.__dict__.get("_plist")
+        if ps is None or self.__dict__.get("_plist_gen") != _PARAM_GEN[0]:
+            ps = list(self.parameters())
+            self.__dict__["_plist"] = ps
+            self.__dict__["_plist_gen"] = _PARAM_GEN[0]
         return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]))
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_plist"] = None
+        return super()._apply(fn, *args, **kwargs)
 
     def _native(self):
         key = self._key()

@@ -264,3 +264,15 @@ def test_liteflownet2_matches_reference_golden(tag, dev):
     _check(flow.cpu().numpy(), want, tag)
     full = pivlfn.estimate(net, i1, i2, tensor=True)
     assert tuple(full.shape) == (i1.shape[0], 2, i1.shape[2], i1.shape[3])
+
+
+def test_replacing_a_parameter_object_takes_effect(dev):
+    """The native handle is keyed on a cached parameter list; assigning a NEW Parameter object must invalidate it."""
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    a, b = synth.particle_batch(1, 64, 64, seed=8)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    before = net(i1, i2).clone()
+    mod = net.NetC.conv1._modules["0"]
+    mod.weight = torch.nn.Parameter(mod.weight.detach() * 0.5, requires_grad=False)
+    after = net(i1, i2)
+    assert not torch.equal(before, after)
