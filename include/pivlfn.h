@@ -37,8 +37,13 @@ typedef struct {
 const char *pivlfn_last_error(void);
 int         pivlfn_abi_version(void);
 
-/* Benchmark-only tuning knobs (kernel variant selection for in-process A/B timing); defaults are the shipped path. */
+/* The library keeps no process-global mutable state: entry points may be called concurrently from several threads, on
+ * several devices and streams (one pivlfn_net / pivlfn_conv handle per device; a handle is used by one thread at a time).
+ * Kernel-variant knobs for in-process A/B timing exist only in the separate tools build (libpivlfn_tools.so, compiled with
+ * -DPIVLFN_TOOLS and loaded by tools/ alone); libpivlfn.so does not export pivlfn_tune. */
+#ifdef PIVLFN_TOOLS
 int         pivlfn_tune(int knob, int value);
+#endif
 
 /* ---- custom op: replaces _FunctionCorrelation.forward, src/correlation.py:287-344 (+ kernels :9-104)
  * first, second: NCHW [B,C,H,W]; out: NCHW [B,49,ceil(H/stride),ceil(W/stride)];

@@ -1,4 +1,6 @@
 // extern "C" surface of libpivlfn.so (declared in include/pivlfn.h).
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include "common.h"
 
@@ -8,7 +10,24 @@ struct pivlfn_conv;
 namespace pivlfn {
 
 static thread_local char g_err[512] = "";
-int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef PIVLFN_TOOLS
+int g_knob[16] = {0};
+#endif
+
+// hipFuncSetAttribute is per device: the opt-in is remembered per (call site, device).  Fast path: one relaxed atomic read.
+int ensure_dyn_lds(LdsAttr &slot, const void *fn, int bytes)
+{
+    static std::mutex mu;
+    int dev = 0;
+    PIV_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device ordinal %d out of range", dev); return PIVLFN_ERR_ARG; }
+    if (__atomic_load_n(&slot.bytes[dev], __ATOMIC_ACQUIRE) >= bytes) return PIVLFN_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    if (slot.bytes[dev] >= bytes) return PIVLFN_OK;
+    PIV_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    __atomic_store_n(&slot.bytes[dev], bytes, __ATOMIC_RELEASE);
+    return PIVLFN_OK;
+}
 
 void set_error(const char *fmt, ...)
 {
@@ -44,12 +63,14 @@ extern "C" {
 const char *pivlfn_last_error(void) { return g_err; }
 int pivlfn_abi_version(void) { return 1; }
 
+#ifdef PIVLFN_TOOLS
 int pivlfn_tune(int knob, int value)
 {
-    if (knob < 0 || knob >= 8) { set_error("tune: knob %d out of range", knob); return PIVLFN_ERR_ARG; }
+    if (knob < 0 || knob >= 16) { set_error("tune: knob %d out of range", knob); return PIVLFN_ERR_ARG; }
     g_knob[knob] = value;
     return PIVLFN_OK;
 }
+#endif
 
 int pivlfn_corr_fwd(const float *first, const float *second, float *out, int B, int C, int H, int W, int stride, void *stream)
 {

@@ -1,18 +1,36 @@
 #!/bin/bash
 # Builds libpivlfn.so (gfx950) in-tree: piv_liteflownet-pytorch_amd/pivlfn/libpivlfn.so
+#   build.sh          the production library (every object rebuilt when ANY source/header of csrc/ or include/ is newer)
+#   build.sh tools    additionally tools/libpivlfn_tools.so: -DPIVLFN_TOOLS -DPIVLFN_STAMPS (A/B knobs, ablation masks, in-kernel
+#                     stamps); only tools/*.py load it
 set -e
 cd "$(dirname "$0")"
-OUT=../pivlfn/libpivlfn.so
-OBJ=../../build/obj
-mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $PIVLFN_EXTRA_FLAGS"   # PIVLFN_EXTRA_FLAGS=-DPIVLFN_STAMPS: instrumented build for tools/bench_ops.py conv_stamps
-pids=()
-for f in conv_mfma conv_f16 conv_head warp_corr corr_bwd ops net api; do
-  if [ ! -f "$OBJ/$f.o" ] || [ "$f.hip" -nt "$OBJ/$f.o" ] || [ common.h -nt "$OBJ/$f.o" ] || [ ../../include/pivlfn.h -nt "$OBJ/$f.o" ]; then
-    hipcc $FLAGS -c "$f.hip" -o "$OBJ/$f.o" &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]}"; do wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/conv_mfma.o "$OBJ"/conv_f16.o "$OBJ"/conv_head.o "$OBJ"/warp_corr.o "$OBJ"/corr_bwd.o "$OBJ"/ops.o "$OBJ"/net.o "$OBJ"/api.o
-echo "built $OUT"
+SRCS="conv_mfma conv_f16 conv_head warp_corr corr_bwd ops net api"
+build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags
+  local OBJ="$1" OUT="$2"
+  mkdir -p "$OBJ"
+  local FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $3 $PIVLFN_EXTRA_FLAGS"
+  # a change to any header (or to the flags) rebuilds everything: no stale objects
+  local STAMP="$OBJ/.flags"
+  if [ ! -f "$STAMP" ] || [ "$(cat "$STAMP")" != "$FLAGS" ]; then rm -f "$OBJ"/*.o; echo "$FLAGS" > "$STAMP"; fi
+  local hdr_new=0
+  for h in *.h ../../include/*.h build.sh; do
+    for o in "$OBJ"/*.o; do [ -f "$o" ] && [ "$h" -nt "$o" ] && hdr_new=1; done
+  done
+  [ "$hdr_new" = 1 ] && rm -f "$OBJ"/*.o
+  local pids=() objs=()
+  for f in $SRCS; do
+    objs+=("$OBJ/$f.o")
+    if [ ! -f "$OBJ/$f.o" ] || [ "$f.hip" -nt "$OBJ/$f.o" ]; then
+      hipcc $FLAGS -c "$f.hip" -o "$OBJ/$f.o" &
+      pids+=($!)
+    fi
+  done
+  for p in "${pids[@]}"; do wait "$p"; done
+  hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
+  echo "built $OUT"
+}
+build_one ../../build/obj ../pivlfn/libpivlfn.so ""
+if [ "$1" = "tools" ]; then
+  build_one ../../build/obj_tools ../../tools/libpivlfn_tools.so "-DPIVLFN_TOOLS -DPIVLFN_STAMPS"
+fi

@@ -10,8 +10,20 @@ namespace pivlfn {
 
 void set_error(const char *fmt, ...);
 
-// Tuning knobs for A/B measurements (pivlfn_tune): 0 = warp_corr variant, 1 = conv variant.
-extern int g_knob[8];
+// Tuning knobs for in-process A/B measurements exist only in the tools build (libpivlfn_tools.so, -DPIVLFN_TOOLS, loaded
+// by tools/ alone): 0 = warp_corr variant, 1 = conv variant bits, 2/3/7 = ablation masks, 5/6 = stamp buffer address.
+// In the production library every knob is the compile-time constant 0: no process-global mutable state.
+#ifdef PIVLFN_TOOLS
+extern int g_knob[16];
+#define PIV_KNOB(i) (pivlfn::g_knob[i])
+#else
+#define PIV_KNOB(i) 0
+#endif
+
+// Opt-in to > 64 KiB of dynamic LDS for kernel `fn`, once per (call site, device); thread-safe.  `slot` is a zero-initialised
+// static at the call site.
+struct LdsAttr { int bytes[64]; };
+int ensure_dyn_lds(LdsAttr &slot, const void *fn, int bytes);
 
 #define PIV_CHECK_HIP(expr)                                                                  \
     do {                                                                                     \

@@ -278,12 +278,8 @@ static int launch_h(const ConvParamsH &p, hipStream_t st)
     const size_t lds = ((size_t)PH * PW * HPITCH + (size_t)p.KH * p.KW * 2 * BN * 8) * sizeof(_Float16) + BN * sizeof(float);
     PIV_REQUIRE(lds <= 160 * 1024, "conv_f16: LDS tile of %zu bytes exceeds 160 KiB (k=%dx%d s=%d)", lds, p.KH, p.KW, p.S);
     PIV_REQUIRE(PH * PW * 2 <= 256 * PM && p.KH * p.KW * 2 * BN <= 256 * WM, "conv_f16: internal staging bound exceeded");
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_f16_kernel<MT, NT, PM, WM>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_f16_kernel<MT, NT, PM, WM>), 160 * 1024)) return rc;
     const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
     dim3 grid(tiles, p.cout_pad / BN);
     hipLaunchKernelGGL((conv_f16_kernel<MT, NT, PM, WM>), grid, dim3(256), lds, st, p);
@@ -294,8 +290,8 @@ static int launch_h(const ConvParamsH &p, hipStream_t st)
 int launch_conv_h(const ConvParamsH &p_in, hipStream_t st)
 {
     ConvParamsH p = p_in;
-    p.dbg = g_knob[3];
-    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)g_knob[6] << 32) | (unsigned)g_knob[5]);   // tools only
+    p.dbg = PIV_KNOB(3);
+    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.nchunk >= 1, "conv_f16: bad segment description");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0, "conv_f16: bad output channel counts");
     for (int i = 0; i < p.nseg; ++i)
@@ -309,7 +305,7 @@ int launch_conv_h(const ConvParamsH &p_in, hipStream_t st)
     if (s1_3x3) {
         if (nt == 4) return big ? launch_h<4, 4, 5, 9>(p, st) : launch_h<2, 4, 5, 9>(p, st);
         // 64 channels: the 8-row tile fits twice per CU (128->64 at 1024^2: 242 us vs 293 us for the 16-row tile)
-        if (nt == 2) return (big && (g_knob[1] & 64)) ? launch_h<4, 2, 5, 9>(p, st) : launch_h<2, 2, 5, 9>(p, st);
+        if (nt == 2) return (big && (PIV_KNOB(1) & 64)) ? launch_h<4, 2, 5, 9>(p, st) : launch_h<2, 2, 5, 9>(p, st);
         return big ? launch_h<4, 1, 5, 9>(p, st) : launch_h<2, 1, 5, 9>(p, st);
     }
     // everything else (stride 2, 7x7, separable k x 1 / 1 x k): 8-row tiles, the larger staging class

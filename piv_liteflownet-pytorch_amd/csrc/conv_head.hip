@@ -83,18 +83,15 @@ static int launch_head_t(const float *x, const float *w, float b0, float b1, con
 {
     constexpr int PW = 16 + K - 1;
     const size_t lds = ((size_t)PW * PW * 32 + K * K * 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_head_kernel<K, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_head_kernel<K, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+    static LdsAttr attr_a, attr_b;
+    if (lds > 64 * 1024) {
+        if (int rc = ensure_dyn_lds(attr_a, reinterpret_cast<const void *>(conv_head_kernel<K, false>), (int)lds)) return rc;
+        if (int rc = ensure_dyn_lds(attr_b, reinterpret_cast<const void *>(conv_head_kernel<K, true>), (int)lds)) return rc;
     }
     const int nblk = cdiv(W, 16) * cdiv(H, 16) * B;
     // (per image, so that a pair's flow never depends on its batch mates -- the two variants differ in nothing but the weight path,
     //  and produce the same bits, but the rule costs nothing)
-    if (cdiv(W, 16) * cdiv(H, 16) <= 512 && !(g_knob[1] & 1024))
+    if (cdiv(W, 16) * cdiv(H, 16) <= 512 && !(PIV_KNOB(1) & 1024))
         hipLaunchKernelGGL((conv_head_kernel<K, true>), dim3(nblk), dim3(256), lds, st, x, w, b0, b1, res4, out4, B, H, W);
     else
         hipLaunchKernelGGL((conv_head_kernel<K, false>), dim3(nblk), dim3(256), lds, st, x, w, b0, b1, res4, out4, B, H, W);

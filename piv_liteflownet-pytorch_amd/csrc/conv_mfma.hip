@@ -436,12 +436,8 @@ static int launch_t2(const ConvParams &p, hipStream_t st)
     const size_t lds = ((size_t)PH * PW * PIXP + (size_t)p.KH * p.KW * 2 * BN * 4) * sizeof(float);
     PIV_REQUIRE(lds <= 160 * 1024, "conv: LDS tile of %zu bytes exceeds 160 KiB (k=%dx%d s=%d)", lds, p.KH, p.KW, p.S);
     PIV_REQUIRE(PH * PW * 2 <= 256 * PMAX && p.KH * p.KW * 2 * BN <= 256 * WMAX, "conv: internal staging bound exceeded");
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma2_kernel<MT, NT, PMAX, WMAX>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_mfma2_kernel<MT, NT, PMAX, WMAX>), 160 * 1024)) return rc;
     const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
     const int nz = p.ksplit > 1 ? p.ksplit : 1;
     dim3 grid(tiles, p.cout_pad / BN, nz);
@@ -575,18 +571,15 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(const ConvParams p)
 // Applies to: one K chunk that is a 4-channel tail, >= 16 taps, no residual, 32-channel output blocks, enough tiles.
 static int launch_conv_k1(const ConvParams &p, hipStream_t st)
 {
-    if (p.nchunk != 1 || !p.tail || p.res || p.KH * p.KW < 16 || p.nseg != 1 || (g_knob[1] & 256)) return -1;
+    if (p.nchunk != 1 || !p.tail || p.res || p.KH * p.KW < 16 || p.nseg != 1 || (PIV_KNOB(1) & 256)) return -1;
     const int PH = 7 * p.S + p.KH, PW = 31 * p.S + p.KW;
     if (PH * PW * 2 > 256 * 5) return -1;
     const size_t lds = ((size_t)PH * PW * PIXP + (size_t)p.KH * p.KW * 2 * 32 * 4) * sizeof(float);
     if (lds > 80 * 1024) return -1;
     const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B;
     if (tiles < 1024) return -1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_k1_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_k1_kernel<5>), 80 * 1024)) return rc;
     const int nby = p.cout_pad / 32;
     hipLaunchKernelGGL((conv_k1_kernel<5>), dim3(std::max(1, 512 / nby), nby), dim3(256), lds, st, p);
     PIV_CHECK_HIP(hipGetLastError());
@@ -597,8 +590,8 @@ static int launch_conv_k1(const ConvParams &p, hipStream_t st)
 static int launch_conv2(const ConvParams &p_in, hipStream_t st)
 {
     ConvParams p = p_in;
-    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)g_knob[6] << 32) | (unsigned)g_knob[5]);   // tools only
-    p.dbg = g_knob[7];
+    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only
+    p.dbg = PIV_KNOB(7);
     const int taps = p.KH * p.KW;
     // Split-K when one image has too few tiles for the chip and the K loop is long enough to be worth sharing.  Decided from
     // the per-image count of canonical (4 rows x 32 px x 32 channels) tiles only -- never from the batch size or from the tile
@@ -607,7 +600,7 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
         const int nfull = p.nchunk - p.tail;
         const long blocks1 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 4) * (p.cout_pad / 32);
         p.ksplit = 1;
-        if (p.scratch && blocks1 <= 128 && nfull >= 4 && !(g_knob[1] & 128)) {
+        if (p.scratch && blocks1 <= 128 && nfull >= 4 && !(PIV_KNOB(1) & 128)) {
             p.ksplit = (int)std::min<long>(std::min(8, nfull / 2), std::max<long>(1, 512 / blocks1));
             if ((size_t)p.B * p.Ho * p.Wo * p.cout_pad * p.ksplit > p.scratch_floats) p.ksplit = 1;   // standalone layers with a small scratch only
         }
@@ -620,7 +613,7 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
         if (p.cout_pad % (cand * 32)) continue;
         if (px_blocks1 * (p.cout_pad / (cand * 32)) >= 256 || cand == 1) { nt = cand; break; }
     }
-    if ((g_knob[1] & 8) && nt == 4) nt = 2;              // A/B: 64-channel N tiles (three workgroups per CU) for 128-channel layers
+    if ((PIV_KNOB(1) & 8) && nt == 4) nt = 2;              // A/B: 64-channel N tiles (three workgroups per CU) for 128-channel layers
     int mt = (px_blocks1 / 2) * (p.cout_pad / (nt * 32)) >= 512 ? 2 : 1;
     auto need = [&](int mt_, int nt_, int &pm, int &wm) {
         const int PH = (4 * mt_ - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
@@ -659,12 +652,8 @@ static int launch_t(const ConvParams &p, hipStream_t st)
     const int PH = (TH - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
     const size_t lds = ((size_t)PH * PW * PIXP + (size_t)p.KH * p.KW * 2 * BN * 4) * sizeof(float);
     PIV_REQUIRE(lds <= 160 * 1024, "conv: LDS tile of %zu bytes exceeds 160 KiB (k=%dx%d s=%d)", lds, p.KH, p.KW, p.S);
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<MT, NT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        attr_set = 160 * 1024;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_mfma_kernel<MT, NT>), 160 * 1024)) return rc;
     const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
     dim3 grid(tiles, p.cout_pad / BN);
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), lds, st, p);
@@ -679,7 +668,7 @@ int launch_conv(const ConvParams &p, hipStream_t st)
     PIV_REQUIRE(p.B > 0 && p.H > 0 && p.W > 0 && p.Ho > 0 && p.Wo > 0, "conv: empty shape");
     for (int s = 0; s < p.nseg; ++s)
         PIV_REQUIRE(p.seg[s].cload % 4 == 0 && p.seg[s].stride % 4 == 0 && p.seg[s].ptr, "conv: segment %d misaligned", s);
-    if (!(g_knob[1] & 2)) {               // shipped path: v2 (register prefetch); knob bit 1 forces v1 for A/B
+    if (!(PIV_KNOB(1) & 2)) {               // shipped path: v2 (register prefetch); knob bit 1 forces v1 for A/B
         const int rk = launch_conv_k1(p, st);
         if (rk >= 0) return rk;
         const int rc = launch_conv2(p, st);

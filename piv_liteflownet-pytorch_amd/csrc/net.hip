@@ -643,7 +643,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             }
             hid = src;
         }
-        if (g_knob[1] & 1)    // A/B: heads on the matrix cores (30 of 32 output columns wasted)
+        if (PIV_KNOB(1) & 1)    // A/B: heads on the matrix cores (30 of 32 output columns wasted)
             RUN(conv(lw.M[net->nstack], {{hid, 32, 32}}, bf.flowM, 4, 4, fup, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
         else
             RUN(launch_conv_head(hid, lw.headM, lw.hbM[0], lw.hbM[1], fup, bf.flowM, B, hh, ww, k, st));
@@ -663,7 +663,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
             }
             hid = src;
         }
-        if (g_knob[1] & 1)
+        if (PIV_KNOB(1) & 1)
             RUN(conv(lw.S[net->nstack], {{hid, 32, 32}}, bf.flowS, 4, 4, bf.flowM, 4, 0, B, hh, ww, 1, k / 2, k / 2, st));
         else
             RUN(launch_conv_head(hid, lw.headS, lw.hbS[0], lw.hbS[1], bf.flowM, bf.flowS, B, hh, ww, k, st));

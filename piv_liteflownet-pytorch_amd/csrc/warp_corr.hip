@@ -43,7 +43,39 @@ struct WcParams {
     float scale;
     int B, C, H, W, s, Ho, Wo, leaky;
     int dbg;      // ablation mask for tools/bench_ops.py (0 in production): 1 skip dot products, 2 skip gathers, 4 skip store, 8 exit at entry
+    unsigned long long *stamps;   // tools build only: per-workgroup phase stamps (16 u64 per record, 2 records per workgroup); nullptr in production
 };
+
+// In-kernel phase stamps (tools build, -DPIVLFN_STAMPS): wave 0 and wave 8 of every workgroup record s_memtime at the phase
+// boundaries and s_memrealtime (100 MHz, chip-wide) at entry and exit, so that a launch's timeline can be laid out across CUs.
+#ifdef PIVLFN_STAMPS
+#define WC_STAMP_DECL                                                                             \
+    unsigned long long st_[12];                                                                   \
+    int st_n_ = 0;                                                                                \
+    const bool st_on_ = p.stamps != nullptr && (threadIdx.x == 0 || threadIdx.x == 512);          \
+    unsigned long long st_rt0_ = 0;                                                               \
+    if (st_on_) st_rt0_ = __builtin_amdgcn_s_memrealtime()
+#define WC_STAMP()                                                                                \
+    do {                                                                                          \
+        if (st_on_ && st_n_ < 12) st_[st_n_] = __builtin_amdgcn_s_memtime();                      \
+        ++st_n_;                                                                                  \
+    } while (0)
+#define WC_STAMP_FLUSH()                                                                          \
+    do {                                                                                          \
+        if (st_on_) {                                                                             \
+            unsigned long long *o_ = p.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x ? 1 : 0)) * 16; \
+            for (int i_ = 0; i_ < 12; ++i_) o_[i_] = i_ < st_n_ ? st_[i_] : 0ull;                 \
+            o_[12] = st_rt0_;                                                                     \
+            o_[13] = __builtin_amdgcn_s_memrealtime();                                            \
+            o_[14] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); /* HW_REG_XCC_ID */ \
+            o_[15] = (unsigned long long)st_n_;                                                   \
+        }                                                                                         \
+    } while (0)
+#else
+#define WC_STAMP_DECL do { } while (0)
+#define WC_STAMP() do { } while (0)
+#define WC_STAMP_FLUSH() do { } while (0)
+#endif
 
 
 template <int CC, bool NHWC>
@@ -267,13 +299,18 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
 
+    WC_STAMP_DECL;
+    WC_STAMP();
+    const int a_iy = (oy0 + tid / TP - 3) * p.s, a_ix = (ox0 + tid % TP - 3) * p.s;
+    const bool a_in = tid < NPOS && a_iy >= 0 && a_iy < p.H && a_ix >= 0 && a_ix < p.W;
+    float2 uv = {0.f, 0.f};
+    if (HASFLOW && a_in) uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)a_iy * p.W + a_ix) * 4);
     if (tid < NPOS) {
-        const int iy = (oy0 + tid / TP - 3) * p.s, ix = (ox0 + tid % TP - 3) * p.s;
+        const int iy = a_iy, ix = a_ix;
         unsigned o0 = OOB, o1 = OOB, o2 = OOB, o3 = OOB;
         float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        if (a_in) {
             if (HASFLOW) {
-                const float2 uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)iy * p.W + ix) * 4);
                 const Taps t = make_taps((float)ix + uv.x * p.scale, (float)iy + uv.y * p.scale, p.H, p.W);
                 o0 = t.o00 < 0 ? OOB : (unsigned)t.o00 * pix_bytes; o1 = t.o01 < 0 ? OOB : (unsigned)t.o01 * pix_bytes;
                 o2 = t.o10 < 0 ? OOB : (unsigned)t.o10 * pix_bytes; o3 = t.o11 < 0 ? OOB : (unsigned)t.o11 * pix_bytes;
@@ -472,6 +509,8 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
             *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) =
                 *reinterpret_cast<const f32x4 *>(ost + pp * OUTC + 4 * q);
     }
+    WC_STAMP();
+    WC_STAMP_FLUSH();
 }
 
 template <bool HASFLOW, bool R2>
@@ -479,12 +518,8 @@ static int launch_wc3(const WcParams &p, hipStream_t st)
 {
     const size_t lds = ((size_t)2 * (NPOS + 64) * 32 + 8 * NPOS) * sizeof(float);
     PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
-    static bool attr = false;
-    if (!attr) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_v3_kernel<HASFLOW, R2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_v3_kernel<HASFLOW, R2>), (int)lds)) return rc;
     const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
     if (g_ev_start) {
         hipExtLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW, R2>), dim3(nblk), dim3(512), lds, st, g_ev_start, g_ev_stop, 0, p);
@@ -530,6 +565,8 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     const int b = bid / tiles_y;
     const int ox0 = tx * TO, oy0 = ty * TO;
     if (p.dbg & 8) return;
+    WC_STAMP_DECL;
+    WC_STAMP();                                   // 0: entry
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id 0..15, provably uniform
     const size_t img = (size_t)p.H * p.W;
@@ -544,13 +581,20 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     const unsigned f1off = (foy < p.Ho && fox < p.Wo) ? (unsigned)((foy * p.s) * p.W + fox * p.s) * pix_bytes + 16u * q16 : OOB;
     f32x4 xf = bload(rs1, f1off);
 
+    // phase A: flow at this thread's position; the L2 prefetch of the tile's f2 footprint goes out behind it
+    const int a_iy = (oy0 + tid / TP - 3) * p.s, a_ix = (ox0 + tid % TP - 3) * p.s;
+    const bool a_in = tid < NPOS && a_iy >= 0 && a_iy < p.H && a_ix >= 0 && a_ix < p.W;
+    float2 uv = {0.f, 0.f};
+    // (Measured and dropped: touching the tile's f2 footprint from waves 4..15 while the flow is in flight, as an L2 prefetch.
+    // The launch got 2.5 us slower in the network and 4 us slower from cold caches: with every CU asking at once the gathers
+    // are bound by bytes per CU through the miss path, not by latency, and a touched line costs what a gathered one does.)
+    if (HASFLOW && a_in) uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)a_iy * p.W + a_ix) * 4);
     if (tid < NPOS) {
-        const int iy = (oy0 + tid / TP - 3) * p.s, ix = (ox0 + tid % TP - 3) * p.s;
+        const int iy = a_iy, ix = a_ix;
         unsigned o0 = OOB, o1 = OOB, o2 = OOB, o3 = OOB;
         float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        if (a_in) {
             if (HASFLOW) {
-                const float2 uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)iy * p.W + ix) * 4);
                 const Taps t = make_taps((float)ix + uv.x * p.scale, (float)iy + uv.y * p.scale, p.H, p.W);
                 o0 = t.o00 < 0 ? OOB : (unsigned)t.o00 * pix_bytes; o1 = t.o01 < 0 ? OOB : (unsigned)t.o01 * pix_bytes;
                 o2 = t.o10 < 0 ? OOB : (unsigned)t.o10 * pix_bytes; o3 = t.o11 < 0 ? OOB : (unsigned)t.o11 * pix_bytes;
@@ -563,7 +607,9 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
         tapo[0 * NPOS + tid] = o0; tapo[1 * NPOS + tid] = o1; tapo[2 * NPOS + tid] = o2; tapo[3 * NPOS + tid] = o3;
         tapw[0 * NPOS + tid] = w0; tapw[1 * NPOS + tid] = w1; tapw[2 * NPOS + tid] = w2; tapw[3 * NPOS + tid] = w3;
     }
+    WC_STAMP();                                   // 1: flow read, taps written (waves 0..3 only do that work)
     __syncthreads();
+    WC_STAMP();                                   // 2: barrier 1 passed
     // left-over items: positions 192..195 x 16 quads = 64 items; thread t < 256 owns tap (t&3) of item (t>>2)
     const int rem_pos = 192 + (tid >> 6), rem_q = (tid >> 2) & 15;
     const unsigned rem_off = tid < 256 ? tapo[(tid & 3) * NPOS + rem_pos] + 16u * rem_q : OOB;
@@ -591,6 +637,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
             xr = bload(rs2, rem_off + (unsigned)c0 * 4u);
             if (c0) xf = bload(rs1, f1off + (unsigned)c0 * 4u);
         }
+        WC_STAMP();                                   // 3: gathers issued
         if (c0) __syncthreads();          // previous chunk's dot products are done with the LDS image
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -610,7 +657,9 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
             if ((tid & 3) == 0) *reinterpret_cast<f32x4 *>(f2w + rem_pos * PP + 4 * (rem_q ^ swz16(rem_pos))) = v;
         }
         *reinterpret_cast<f32x4 *>(f1t + pq * PP + 4 * (q16 ^ (pq & 15))) = xf;
+        WC_STAMP();                                   // 4: gathers arrived, blended, written to LDS
         __syncthreads();
+        WC_STAMP();                                   // 5: barrier 2 passed
 
         if (!(p.dbg & 1)) {
             int lane_l = lane;
@@ -646,7 +695,9 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
         }
     }
 
+    WC_STAMP();                                   // 6: dot products done
     __syncthreads();
+    WC_STAMP();                                   // 7: barrier 3 passed
     float *ost = smem;                           // [64][56], exact zeros in lanes 49..55
     const float cf = (float)p.C;
 #pragma unroll
@@ -663,6 +714,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
         for (int d = 49; d < OUTC; ++d) ost[lane * OUTC + d] = 0.f;
     }
     __syncthreads();
+    WC_STAMP();                                   // 8: transposed, barrier 4 passed
     if (tid < 64 * (OUTC / 4) && !(p.dbg & 4)) {
         const int pp = tid / (OUTC / 4), q = tid - pp * (OUTC / 4);
         const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
@@ -670,6 +722,8 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
             *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) =
                 *reinterpret_cast<const f32x4 *>(ost + pp * OUTC + 4 * q);
     }
+    WC_STAMP();                                   // 9: stores issued
+    WC_STAMP_FLUSH();
 }
 
 template <bool HASFLOW>
@@ -677,12 +731,8 @@ static int launch_wc4(const WcParams &p, hipStream_t st)
 {
     const size_t lds = ((size_t)(NPOS + 64) * 64 + 8 * NPOS) * sizeof(float);
     PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
-    static bool attr = false;
-    if (!attr) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_v4_kernel<HASFLOW>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_v4_kernel<HASFLOW>), (int)lds)) return rc;
     const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
     if (g_ev_start) {
         hipExtLaunchKernelGGL((warp_corr_v4_kernel<HASFLOW>), dim3(nblk), dim3(1024), lds, st, g_ev_start, g_ev_stop, 0, p);
@@ -698,19 +748,16 @@ template <int CC, bool NHWC>
 static int launch_wc(const WcParams &p, hipStream_t st)
 {
     const size_t lds = (size_t)(NPOS + 64) * (CC + 4) * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        PIV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(warp_corr_kernel<CC, NHWC>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    static LdsAttr attr;
+    if (lds > 64 * 1024)
+        if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_kernel<CC, NHWC>), (int)lds)) return rc;
     const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
     hipLaunchKernelGGL((warp_corr_kernel<CC, NHWC>), dim3(nblk), dim3(256), lds, st, p);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
 
-static int wc_variant() { return g_knob[0]; }
+static int wc_variant() { return PIV_KNOB(0); }
 
 int launch_warp_corr(const float *f1, const float *f2, const float *flow, float flow_scale, float *out,
                      int B, int C, int H, int W, int stride, int leaky, bool nhwc, hipStream_t st)
@@ -718,7 +765,8 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
     PIV_REQUIRE(f1 && f2 && out, "warp_corr: null pointer");
     PIV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "warp_corr: empty shape B=%d C=%d H=%d W=%d", B, C, H, W);
     PIV_REQUIRE(stride >= 1 && stride <= 4, "warp_corr: stride=%d unsupported", stride);
-    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, g_knob[2]};
+    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, PIV_KNOB(2),
+               reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(10) << 32) | (unsigned)PIV_KNOB(9))};
     if (nhwc) {
         PIV_REQUIRE(C % 32 == 0, "warp_corr (channels-last): C=%d must be a multiple of 32", C);
         const int variant = wc_variant();

@@ -1,2 +1,2 @@
-"""Alias of pivlfn.inference under the reference's import path (inference.py: `from inference import estimate`)."""
-from pivlfn.inference import estimate  # noqa: F401
+"""Alias of pivlfn.inference under the reference's import path (run.py:16: `from inference import Inference, estimate`)."""
+from pivlfn.inference import Inference, estimate  # noqa: F401

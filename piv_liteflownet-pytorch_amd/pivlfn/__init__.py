@@ -7,7 +7,7 @@ fallback: importing works anywhere, but every op raises if the library or a GPU 
 """
 from .correlation import FunctionCorrelation, ModuleCorrelation          # noqa: F401
 from .models import LiteFlowNet, LiteFlowNet2, Network, backwarp, hui_liteflownet, piv_liteflownet  # noqa: F401
-from .inference import estimate                                          # noqa: F401
+from .inference import Inference, estimate                               # noqa: F401
 
 __all__ = ["FunctionCorrelation", "ModuleCorrelation", "LiteFlowNet", "LiteFlowNet2", "Network", "backwarp",
-           "hui_liteflownet", "piv_liteflownet", "estimate"]
+           "hui_liteflownet", "piv_liteflownet", "estimate", "Inference"]

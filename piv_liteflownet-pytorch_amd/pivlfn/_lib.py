@@ -19,7 +19,6 @@ class Tensor(ctypes.Structure):
 SIGNATURES = {
     "pivlfn_last_error": (ctypes.c_char_p, []),
     "pivlfn_abi_version": (ctypes.c_int, []),
-    "pivlfn_tune": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "pivlfn_corr_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "pivlfn_corr_bwd": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "pivlfn_conv2d_nhwc_f16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),

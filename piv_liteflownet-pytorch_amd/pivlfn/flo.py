@@ -10,63 +10,75 @@ import io
 import os
 import queue
 import threading
-from typing import Union
 
 import numpy as np
 
 TAG_FLOAT = 202021.25                  # src/utils_plot.py:15
+_HEADER = np.dtype([("tag", "<f4"), ("width", "<i4"), ("height", "<i4")])      # 12 bytes, little endian
+_MAX_SIDE = 100000
 
 
-def read_flow(filename: Union[str, io.BufferedReader], use_stereo: bool = False) -> np.ndarray:
-    """Returns [H, W, 2] (or 3 with use_stereo) float32.  Error behaviour of src/utils_plot.py:26-73 (AssertionError)."""
-    if not isinstance(filename, io.BufferedReader):
-        if not isinstance(filename, str):
-            raise AssertionError(f"Input [{filename}] is not a string")
-        if not os.path.isfile(filename):
-            raise AssertionError(f"Path [{filename}] does not exist")
-        if filename.split(".")[-1] != "flo":
-            raise AssertionError(f"File extension [flo] required, [{filename.split('.')[-1]}] given")
-        f = open(filename, "rb")
+def _fail(msg: str):
+    # the reference signals every malformed-file condition with AssertionError; callers that catch it keep working
+    raise AssertionError(msg)
+
+
+def read_flow(source, use_stereo: bool = False) -> np.ndarray:
+    """Middlebury .flo -> float32 [H, W, 2] (3 bands with use_stereo).  `source` is a path ending in .flo or an open binary
+    stream (closed on return, as the reference does).  Same contract as src/utils_plot.py:26-73 for well-formed files; a
+    payload shorter than the header promises is an error here (the reference silently tiles what it got)."""
+    if isinstance(source, io.IOBase):
+        stream = source
     else:
-        f = filename
-    try:
-        tag = np.frombuffer(f.read(4), np.float32, count=1)[0]
-        if not TAG_FLOAT == tag:
-            raise AssertionError(f"Wrong Tag [{tag}]")
-        width = int(np.frombuffer(f.read(4), np.int32, count=1)[0])
-        if not (0 < width < 100000):
-            raise AssertionError(f"Illegal width [{width}]")
-        height = int(np.frombuffer(f.read(4), np.int32, count=1)[0])
-        if not (0 < height < 100000):
-            raise AssertionError(f"Illegal height [{height}]")
+        path = os.fspath(source) if isinstance(source, (str, os.PathLike)) else _fail(f"read_flow: {source!r} is neither a path nor a binary stream")
+        if not os.path.isfile(path):
+            _fail(f"read_flow: no such file: {path}")
+        if os.path.splitext(path)[1] != ".flo":
+            _fail(f"read_flow: expected a .flo file, got {path}")
+        stream = open(path, "rb")
+    with stream:
+        raw = stream.read(_HEADER.itemsize)
+        if len(raw) != _HEADER.itemsize:
+            _fail("read_flow: file too short for a .flo header")
+        head = np.frombuffer(raw, dtype=_HEADER)[0]
+        if float(head["tag"]) != TAG_FLOAT:
+            _fail(f"read_flow: bad magic number {float(head['tag'])!r} (want {TAG_FLOAT})")
+        width, height = int(head["width"]), int(head["height"])
+        if not (0 < width < _MAX_SIDE and 0 < height < _MAX_SIDE):
+            _fail(f"read_flow: implausible size {width} x {height}")
         bands = 3 if use_stereo else 2
-        data = np.frombuffer(f.read(bands * width * height * 4), np.float32, count=bands * width * height)
-    finally:
-        f.close()
-    return np.array(data, dtype=np.float32).reshape(height, width, bands)
+        want = bands * width * height
+        payload = np.frombuffer(stream.read(4 * want), dtype="<f4")
+    if payload.size != want:
+        _fail(f"read_flow: payload has {payload.size} of {want} values")
+    return payload.reshape(height, width, bands).astype(np.float32, copy=True)
 
 
 def write_flow(flow: np.ndarray, filename: str) -> None:
-    """flow: [H, W, 2|3] float32 (src/utils_plot.py:120-158, without the optional normalisation)."""
-    assert type(filename) is str, "file is not str (%r)" % str(filename)
-    assert filename[-4:] == ".flo", "file ending is not .flo (%r)" % filename[-4:]
-    height, width, bands = flow.shape
-    assert bands == 2 or bands == 3, "Number of bands = %r != (2 or 3)" % bands
-    with open(filename, "wb") as f:
-        np.array([TAG_FLOAT], dtype=np.float32).tofile(f)
-        np.array([width], dtype=np.int32).tofile(f)
-        np.array([height], dtype=np.int32).tofile(f)
-        np.ascontiguousarray(flow, dtype=np.float32).tofile(f)
+    """[H, W, 2|3] array -> Middlebury .flo (src/utils_plot.py:120-158 without its optional normalisation).  The payload is
+    always written as little-endian float32 (the reference writes the array's own dtype, which only round-trips for float32)."""
+    name = os.fspath(filename)
+    if not name.endswith(".flo"):
+        raise AssertionError(f"write_flow: output name must end in .flo, got {name!r}")
+    arr = np.asarray(flow)
+    if arr.ndim != 3 or arr.shape[2] not in (2, 3):
+        raise AssertionError(f"write_flow: expected [H, W, 2 or 3], got shape {arr.shape}")
+    head = np.zeros(1, dtype=_HEADER)
+    head["tag"], head["width"], head["height"] = TAG_FLOAT, arr.shape[1], arr.shape[0]
+    with open(name, "wb") as f:
+        f.write(head.tobytes())
+        f.write(np.ascontiguousarray(arr, dtype="<f4").tobytes())
 
 
 def flowname_modifier(indir: str, outdir: str, ext: str = "_out.flo", pair: bool = True) -> str:
-    """Output file name for an input image name (src/utils_plot.py:310-318)."""
-    out_name = os.path.splitext(os.path.basename(indir))[0]
+    """Where the flow of input image `indir` goes (src/utils_plot.py:310-318): <outdir>/<stem><ext>, the stem losing its last
+    `_suffix` (`_img1`) for paired inputs."""
+    stem = os.path.splitext(os.path.basename(indir))[0]
     if pair:
-        out_name = str(out_name.rsplit("_", 1)[0]) + ext
-    else:
-        out_name += ext
-    return os.path.join(outdir, out_name)
+        head, sep, _ = stem.rpartition("_")
+        if sep:
+            stem = head
+    return os.path.join(outdir, stem + ext)
 
 
 class FloWriter:

@@ -164,28 +164,35 @@ class PairLoader:
         self._thread.join(timeout=5.0)
 
 
-def stream_pairs(net, loader: PairLoader, device: torch.device, sink: Callable[[np.ndarray, str], None],
-                 estimate_fn: Optional[Callable] = None, in_flight: int = 3) -> int:
+def stream_pairs(net, loader: PairLoader, device: torch.device, sink: Callable[..., None],
+                 estimate_fn: Optional[Callable] = None, in_flight: int = 3,
+                 mods: Optional[Sequence[Tuple[float, float]]] = None) -> int:
     """Drive `estimate` over a PairLoader.  `sink(flow_hw2, name)` is called once per pair, in order; the numpy view it gets
     owns a reference to its (pinned) batch buffer, so an asynchronous writer may keep it.  On a GPU the uploads and
     downloads run on a copy stream and overlap with compute; on the CPU (tests of the host logic, with a stand-in
-    `estimate_fn`) the same code runs synchronously."""
+    `estimate_fn`) the same code runs synchronously.
+    `mods`: (brightness, contrast) factors of run.py -b/-c; every uploaded batch is then estimated once per entry, with both
+    frames modified on the device (pivlfn.imagemod), and the sink is called as `sink(flow_hw2, name, (brightness, contrast))`."""
     if estimate_fn is None:
         from .inference import estimate as estimate_fn      # noqa: N813
+    from .imagemod import image_mod
     on_gpu = device.type == "cuda"
     copy = torch.cuda.Stream(device) if on_gpu else None
-    pending: List[Tuple[Optional[torch.cuda.Event], torch.Tensor, Sequence[str]]] = []
+    pending: List[Tuple[Optional[torch.cuda.Event], torch.Tensor, Sequence[str], Optional[Tuple[float, float]]]] = []
     done = 0
 
     def drain(keep: int) -> None:
         nonlocal done
         while len(pending) > keep:
-            ev, host, names = pending.pop(0)
+            ev, host, names, mod = pending.pop(0)
             if ev is not None:
                 ev.synchronize()
             arr = host.numpy()
             for k, name in enumerate(names):
-                sink(arr[k], name)
+                if mod is None:
+                    sink(arr[k], name)
+                else:
+                    sink(arr[k], name, mod)
             done += len(names)
 
     for names, a8, b8 in loader:
@@ -204,19 +211,21 @@ def stream_pairs(net, loader: PairLoader, device: torch.device, sink: Callable[[
             b_dev.record_stream(main)
         else:
             a_dev, b_dev = a8, b8
-        flow = estimate_fn(net, u8_to_input(a_dev), u8_to_input(b_dev), tensor=True)      # [n,2,H,W]
-        out = flow.permute(0, 2, 3, 1).contiguous()                                      # [n,H,W,2], the .flo layout
-        if on_gpu:
-            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-            copy.wait_stream(main)
-            with torch.cuda.stream(copy):
-                host.copy_(out, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy)
-            out.record_stream(copy)
-            pending.append((ev, host, names))
-        else:
-            pending.append((None, out, names))
-        drain(in_flight - 1)
+        for mod in (mods if mods is not None else (None,)):
+            am, bm = (a_dev, b_dev) if mod is None else (image_mod(a_dev, *mod), image_mod(b_dev, *mod))
+            flow = estimate_fn(net, u8_to_input(am), u8_to_input(bm), tensor=True)           # [n,2,H,W]
+            out = flow.permute(0, 2, 3, 1).contiguous()                                      # [n,H,W,2], the .flo layout
+            if on_gpu:
+                host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+                copy.wait_stream(main)
+                with torch.cuda.stream(copy):
+                    host.copy_(out, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy)
+                out.record_stream(copy)
+                pending.append((ev, host, names, mod))
+            else:
+                pending.append((None, out, names, mod))
+            drain(in_flight - 1)
     drain(0)
     return done

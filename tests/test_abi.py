@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "pivlfn.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef PIVLFN_TOOLS.*?#endif", "", text, flags=re.S)      # tools-build-only declarations are not the boundary
     return sorted(set(re.findall(r"\b(pivlfn_[a-z_0-9]+)\s*\(", text)))
 
 
@@ -30,6 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/pivlfn.h but not exported"
     assert set(_declared()) == set(_lib.SIGNATURES), "ctypes prototypes out of sync with the header"
+    assert not hasattr(lib, "pivlfn_tune"), "the production library must not export the tools-only knob setter"
     loaded = _lib.load()
     assert loaded.pivlfn_abi_version() == 1
     assert loaded.pivlfn_last_error() is not None

@@ -106,3 +106,58 @@ def test_particle_sequence_is_a_pure_function_of_seed_and_frame_index():
     assert not torch.equal(a[0], a[1])
     assert 10.0 < a.float().mean().item() < 80.0               # same seeding density / intensity model as particle_pair
     assert not torch.equal(synth.ParticleSequence(64, 96, seed=6).frames(0, 1), a[:1])
+
+
+def test_inference_alias_exports_the_reference_names():
+    """run.py:16 of the reference does `from inference import Inference, estimate`."""
+    import inference
+    assert inference.Inference is pivlfn.Inference and callable(inference.Inference.parser)
+    inf = inference.Inference(net=None, netname="models/pretrain_torch/PIV-LiteFlowNet-en.paramOnly", output_dir="/o")
+    assert inf.netname == "PIV-LiteFlowNet-en" and inf.default == os.path.join("/o", "PIV-LiteFlowNet-en")
+    with pytest.raises(NotImplementedError):
+        inf.video_parsing(0)
+    with pytest.raises(AssertionError):                         # size mismatch is asserted before anything runs (inference.py:204)
+        import PIL.Image
+        inference.Inference.parser(None, PIL.Image.new("RGB", (8, 8)), PIL.Image.new("RGB", (8, 9)))
+
+
+def test_image_mod_is_bit_identical_to_pil_enhance():
+    """run.py -b/-c: the reference modifies the PIL image with torchvision's adjust_brightness / adjust_contrast, which for PIL
+    inputs are ImageEnhance.Brightness / .Contrast; pivlfn.imagemod restates them on uint8 tensors."""
+    import PIL.Image
+    import PIL.ImageEnhance
+    from pivlfn.imagemod import image_mod, mod_name
+    rng = np.random.default_rng(0)
+    for trial in range(3):
+        a = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+        if trial == 1:
+            a[...] = a[..., :1]                                  # grey frames, as PIV images are
+        for b in (0.0, 0.3, 1.0, 1.5, 2.7):
+            for c in (0.0, 0.25, 1.0, 1.3, 3.0):
+                want = np.asarray(PIL.ImageEnhance.Contrast(PIL.ImageEnhance.Brightness(PIL.Image.fromarray(a)).enhance(b)).enhance(c))
+                got = image_mod(torch.from_numpy(a), b, c).numpy()
+                assert np.array_equal(want, got), (trial, b, c)
+    batch = torch.from_numpy(rng.integers(0, 256, (2, 9, 7, 3), dtype=np.uint8))
+    out = image_mod(batch, 1.2, 0.6)                             # the contrast mean is per frame
+    assert torch.equal(out[0], image_mod(batch[0], 1.2, 0.6)) and torch.equal(out[1], image_mod(batch[1], 1.2, 0.6))
+    assert mod_name(1.0, 1.0) == "100_100" and mod_name(0.5, 1.25) == "050_125"      # run.py:125
+    with pytest.raises(ValueError):
+        image_mod(torch.zeros(4, 4, 3), 1.0, 1.0)
+
+
+def test_run_py_output_layout_and_mod_names():
+    """Output tree of run.py:232-266 and the -b/-c naming of run.py:125-131."""
+    import run
+    lay = run.OutputLayout.of("/out", "PIV-LiteFlowNet-en", "/data/exp7", 0, -1)
+    assert (lay.save, lay.flow, lay.args_file) == ("/out/PIV-LiteFlowNet-en/exp7", "/out/PIV-LiteFlowNet-en/exp7/flow",
+                                                   "/out/PIV-LiteFlowNet-en/exp7/args.txt")
+    lay = run.OutputLayout.of("/out", "net", "/data/exp7/", 5, -1)
+    assert lay.save == "/out/net/exp7-5_end"
+    lay = run.OutputLayout.of("/out", "net", "/data/exp7", 0, 12)
+    assert lay.save == "/out/net/exp7-0_12"
+    lay = run.OutputLayout.of("/out", "net", "/data/stereo3/Left", 0, -1)
+    assert (lay.save, lay.flow, lay.args_file) == ("/out/net/stereo3", "/out/net/stereo3/flow/left", "/out/net/stereo3/args_left.txt")
+    assert run.mod_flow_name("/d/with_under/img_0007.png", "/o", (1.0, 0.5)) == "/o/img_100_050_0007_out.flo"
+    assert run.mod_flow_name("/d/frame7.png", "/o", (1.5, 1.0)) == "/o/frame7_150_100_out.flo"
+    args = run.parser.parse_args(["-i", "a", "b", "-b", "0.5", "1.5", "-c", "2"])
+    assert args.brightness == [0.5, 1.5] and args.contrast == [2.0] and args.model == "piv" and args.input == ["a", "b"]

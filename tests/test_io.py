@@ -82,11 +82,56 @@ def test_run_dataset_pairs_and_sequence(tmp_path):
         Run(str(tmp_path / "nope"))
 
 
-def test_reference_demo_flo_is_readable_when_present():
-    """The reference ships two real .flo files; they exist only in the build container (never on the GPU box)."""
-    p = "/root/reference/images/demo/DNS_turbulence_flow.flo"
-    if not os.path.exists(p):
-        pytest.skip("reference checkout not present")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_reference_demo_flo_fixture():
+    """tests/golden/DNS_turbulence_out.flo is the reference's own network output for its demo pair
+    (/root/reference/images/demo/, a data file, committed as a fixture): the reader must take a real .flo as it is."""
+    p = os.path.join(GOLDEN, "DNS_turbulence_out.flo")
     f = read_flow(p)
     assert f.shape == (256, 256, 2) and f.dtype == np.float32
-    assert -2.7 < f[..., 0].min() < -2.5 and 2.2 < f[..., 0].max() < 2.4        # SURVEY.md section 2, row 20
+    assert abs(float(f[..., 0].min()) - (-2.5557063)) < 1e-6 and abs(float(f[..., 0].max()) - 2.216687) < 1e-6
+    assert abs(float(f[..., 1].min()) - (-2.0943394)) < 1e-6 and abs(float(f[..., 1].max()) - 2.4587212) < 1e-6
+    with open(p, "rb") as stream:                       # an open binary stream is accepted too (and closed)
+        g = read_flow(stream)
+    assert stream.closed and np.array_equal(f, g)
+    ref = "/root/reference/images/demo/DNS_turbulence_out.flo"
+    if os.path.exists(ref):
+        assert open(ref, "rb").read() == open(p, "rb").read()
+
+
+def test_flo_truncated_payload_is_an_error(tmp_path):
+    p = tmp_path / "short.flo"
+    p.write_bytes(struct.pack("<fii", 202021.25, 4, 4) + b"\0" * 40)       # 16 of the 128 payload bytes missing
+    with pytest.raises(AssertionError):
+        read_flow(str(p))
+    q = tmp_path / "dims.flo"
+    q.write_bytes(struct.pack("<fii", 202021.25, 0, 4))
+    with pytest.raises(AssertionError):
+        read_flow(str(q))
+
+
+def test_write_flow_casts_to_float32(tmp_path):
+    flow64 = np.random.default_rng(3).standard_normal((3, 5, 2))
+    write_flow(flow64, str(tmp_path / "d.flo"))
+    assert os.path.getsize(tmp_path / "d.flo") == 12 + 3 * 5 * 2 * 4
+    assert np.array_equal(read_flow(str(tmp_path / "d.flo")), flow64.astype(np.float32))
+
+
+def test_file_listing_order_and_case(tmp_path):
+    """Extension by extension, lower-case spelling before the upper-case one, sorted inside a group; hidden files skipped
+    (glob semantics of src/utils_data.py:13-33)."""
+    for n in ("b.png", "a.png", "c.PNG", "z.jpg", ".hidden.png", "note.txt", "a_img1.tif", "a_img2.tif", "B_img1.TIF"):
+        (tmp_path / n).write_bytes(b"")
+    d = str(tmp_path)
+    got = [os.path.basename(x) for x in image_files_from_folder(d, pair=False)]
+    assert got == ["z.jpg", "a.png", "b.png", "c.PNG", "a_img1.tif", "a_img2.tif", "B_img1.TIF"]
+    assert [os.path.basename(x) for x in image_files_from_folder(d, pair=False, upper=False)] == ["z.jpg", "a.png", "b.png", "a_img1.tif", "a_img2.tif"]
+    assert [os.path.basename(x) for x in image_files_from_folder(d, pair=True)] == ["a_img1.tif", "B_img1.TIF"]
+    assert image_files_from_folder(d, pair=False, n_images=0) == []
+
+
+def test_flowname_modifier_without_underscore():
+    assert flowname_modifier("/d/frame.png", "/o") == os.path.join("/o", "frame_out.flo")
+    assert flowname_modifier("/d/a_b_img1.png", "/o") == os.path.join("/o", "a_b_out.flo")

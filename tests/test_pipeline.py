@@ -123,3 +123,25 @@ def test_close_unblocks_a_full_queue(tmp_path):
     next(iter(loader))
     loader.close()                                                 # producer is blocked on put(); must exit
     assert not loader._thread.is_alive()
+
+
+def test_stream_pairs_with_brightness_contrast_mods(tmp_path):
+    """run.py -b/-c: every pair is estimated once per (brightness, contrast) combination on frames modified on the device
+    (here: the CPU stand-in), in pair-major order, and the sink learns which combination a flow belongs to."""
+    from pivlfn.imagemod import image_mod
+    _write_frames(str(tmp_path), 4)
+    ds = Run(str(tmp_path), is_pair=False)
+    mods = [(1.0, 1.0), (0.5, 1.0), (1.5, 2.0)]
+    got = []
+    loader = PairLoader(ds, 0, len(ds), 2)
+    n = stream_pairs(None, loader, torch.device("cpu"), lambda flow, name, mod: got.append((name, mod, flow.copy())),
+                     estimate_fn=_fake_estimate, mods=mods)
+    loader.close()
+    assert n == 3 * len(mods) and len(got) == 9
+    for name, mod, flow in got:
+        i = ds.name_list.index(name)
+        a = torch.from_numpy(read_image_u8(ds.image_list[i][0]))[None]
+        b = torch.from_numpy(read_image_u8(ds.image_list[i][1]))[None]
+        want = _fake_estimate(None, u8_to_input(image_mod(a, *mod)), u8_to_input(image_mod(b, *mod)))[0].permute(1, 2, 0).numpy()
+        assert np.array_equal(flow, want), (name, mod)
+    assert sorted({m for _, m, _ in got}) == sorted(mods)

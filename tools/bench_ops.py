@@ -13,7 +13,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "piv_liteflownet-pytorch_amd"))
-from pivlfn import _lib  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _toolslib  # noqa: E402
+
+
+def _chk(rc, what=""):
+    _toolslib.check(_toolslib.load(), rc, what)
+
 
 LEVELS = {1: (64, 1024, 2), 2: (64, 512, 2), 3: (64, 256, 2), 4: (96, 128, 1), 5: (128, 64, 1), 6: (192, 32, 1)}
 
@@ -34,7 +40,7 @@ def time_it(fn, n=50, rounds=5):
 
 
 def bench_warp_corr(args):
-    lib = _lib.load()
+    lib = _toolslib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     B = args.batch
@@ -56,7 +62,7 @@ def bench_warp_corr(args):
 
             def fn(v=v, out=out):
                 lib.pivlfn_tune(0, v)
-                _lib.check(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), flow_ptr, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
+                _chk(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), flow_ptr, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
             tmin, tmed = time_it(fn)
             print(f"L{L} B={B} C={C} {n}x{n} s={s} variant {v}: min {tmin:8.2f} us  med {tmed:8.2f} us   "
                   f"{alg / tmin / 1e3:8.1f} GB/s algorithmic ({alg / 1e6:.2f} MB)", flush=True)
@@ -69,7 +75,7 @@ def bench_warp_corr(args):
 
 def bench_wc_ablate(args):
     """Ablation of the shipped warp+correlation kernel (mask bits: 1 no dot products, 2 no gathers, 4 no store, 8 empty)."""
-    lib = _lib.load()
+    lib = _toolslib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     B = args.batch
@@ -83,7 +89,7 @@ def bench_wc_ablate(args):
         out = torch.empty(B, no, no, 56, device=dev)
         for mask in (0, 8, 1, 2, 4, 3, 7):
             def fn():
-                _lib.check(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), fl.data_ptr() if L < 6 else None, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
+                _chk(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), fl.data_ptr() if L < 6 else None, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
             lib.pivlfn_tune(2, mask)
             tmin, tmed = time_it(fn)
             print(f"L{L} B={B} ablation mask {mask}: min {tmin:8.2f} us  med {tmed:8.2f} us", flush=True)
@@ -107,7 +113,7 @@ CONV_SHAPES = [
 
 def bench_conv(args):
     import ctypes
-    lib = _lib.load()
+    lib = _toolslib.load()
     lib.pivlfn_tune(3, args.tune3)
     lib.pivlfn_tune(7, args.tune7)
     dev = torch.device("cuda:0")
@@ -121,7 +127,7 @@ def bench_conv(args):
         w = (torch.randn(co, ci, kh, kw) / (ci * kh * kw) ** 0.5).contiguous()
         b = torch.randn(co).contiguous()
         h = ctypes.c_void_p()
-        _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
+        _chk(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
         x = torch.randn(B, n, n, ci, device=dev)
         no = (n + 2 * (kh // 2) - kh) // s + 1
         mo = (n + 2 * (kw // 2) - kw) // s + 1
@@ -142,11 +148,11 @@ def bench_conv(args):
                 lib.pivlfn_tune(1, (v - 100000) >> 1 if v >= 100000 else v)
                 if v >= 100000:
                     if f16io and ci % 8 == 0:
-                        _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, xh.data_ptr(), ci, 1, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                        _chk(lib.pivlfn_conv2d_nhwc_f16(h, xh.data_ptr(), ci, 1, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
                     else:
-                        _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, x.data_ptr(), ci, 0, y.data_ptr(), ys, 1 if f16io else 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                        _chk(lib.pivlfn_conv2d_nhwc_f16(h, x.data_ptr(), ci, 0, y.data_ptr(), ys, 1 if f16io else 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
                 else:
-                    _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                    _chk(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
             tmin, tmed = time_it(fn, n=10 if flop > 2e10 else 30, rounds=4)
             print(f"{name:28s} B={B} variant {v}: min {tmin:9.1f} us  med {tmed:9.1f} us  {flop / tmin / 1e6:7.1f} TFLOP/s (staged K)", flush=True)
         for v in variants[1:]:
@@ -159,7 +165,7 @@ def bench_conv(args):
 def bench_conv_stamps(args):
     """Phase times of the fp16 conv kernel (wave 0 of every workgroup, s_memtime ticks): where a workgroup's time goes."""
     import ctypes
-    lib = _lib.load()
+    lib = _toolslib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     for name, co, ci, k, s, n, bm in CONV_SHAPES:
@@ -170,7 +176,7 @@ def bench_conv_stamps(args):
         w = (torch.randn(co, ci, kh, kw) / (ci * kh * kw) ** 0.5).contiguous()
         b = torch.randn(co).contiguous()
         h = ctypes.c_void_p()
-        _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
+        _chk(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
         fp32 = args.tune3 == -1                     # --tune3 -1: stamp the fp32 kernel instead
         f16 = ci % 8 == 0 and not fp32
         x = torch.randn(B, n, n, ci, device=dev)
@@ -184,9 +190,9 @@ def bench_conv_stamps(args):
 
         def run():
             if fp32:
-                _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                _chk(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
             else:
-                _lib.check(lib.pivlfn_conv2d_nhwc_f16(h, xin.data_ptr(), ci, 1 if f16 else 0, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                _chk(lib.pivlfn_conv2d_nhwc_f16(h, xin.data_ptr(), ci, 1 if f16 else 0, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
         for _ in range(3):
             run()
         lib.pivlfn_tune(5, ctypes.c_int32(ptr & 0xFFFFFFFF).value)
