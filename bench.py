@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--model", default="piv", choices=["piv", "hui"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed warm runs of the CPU baseline (median reported)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 = the headline path (default); fp16 = BASELINE config #5's fp16-multiplicand conv mode, reported "
                          "under its own metric name, never as the headline")
@@ -70,20 +71,48 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PIVLFN_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(model, size, wts, i1, i2):
+def cpu_baseline(model, size, wts, i1, i2, runs=3):
+    """The oracle (CPU restatement of the reference's forward) on ONE pair of the workload: median of `runs` warm runs after
+    one untimed run, threads = the cores this process may use."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pivlfn_oracle as orc
     nthreads = host_cores()
     torch.set_num_threads(nthreads)
     net = orc.make_net(model, wts, corr="torch")
+    ts = []
     with torch.no_grad():
-        net.forward(i1[:1, :, :64, :64].contiguous(), i2[:1, :, :64, :64].contiguous())    # page in
-        t0 = time.perf_counter()
-        out = net.forward(i1[:1], i2[:1])
-        dt = time.perf_counter() - t0
+        out = net.forward(i1[:1], i2[:1])                                                   # warm-up: pages, thread pool, caches
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            out = net.forward(i1[:1], i2[:1])
+            ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
     return out, {"value": 1.0 / dt, "unit": "image-pairs/s", "cores": nthreads, "kind": "port",
                  "sample": f"1 pair {size}x{size} fp32, oracle/pivlfn_oracle.py (torch {torch.__version__} CPU convs + "
-                           f"slicing correlation), {dt:.2f} s"}
+                           f"slicing correlation); median of {runs} warm runs: {dt:.2f} s (all: {', '.join(f'{t:.2f}' for t in ts)} s)"}
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the roofline kernel: counter traffic from profiles/ is only quoted for the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("piv_liteflownet-pytorch_amd/csrc/warp_corr.hip", "piv_liteflownet-pytorch_amd/csrc/common.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counter_traffic(name):
+    """HBM bytes per launch from the committed --pmc passes (profiles/<name>), or (None, why)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"profiles/{name} not present"
+    try:
+        j = json.load(open(path))
+    except Exception as e:          # noqa: BLE001
+        return None, f"profiles/{name}: {e}"
+    if j.get("kernel_source_sha256_16") != kernel_source_hash():
+        return None, f"profiles/{name} was taken on other kernel sources ({j.get('kernel_source_sha256_16')} != {kernel_source_hash()}): re-run tools/pmc_l3.sh"
+    return j.get("hbm_bytes_per_launch"), f"profiles/{name}"
 
 
 def l3_throughput_regime(dev, batch=8, launches=40):
@@ -156,12 +185,16 @@ def main():
     gathered = [torch.empty(world * B, 2, S // div, S // div, device=gdev) for _ in range(2)] if world > 1 else None
     pending = [None, None]
 
+    wait_s = [0.0]
+
     def step(i):
         flow = net(i1, i2)
         if world > 1:
             k = i & 1
             if pending[k] is not None:
+                tw = time.perf_counter()
                 pending[k].wait()
+                wait_s[0] += time.perf_counter() - tw
             if backend == "nccl":
                 pending[k] = dist.all_gather_into_tensor(gathered[k], flow, async_op=True)
             else:
@@ -183,18 +216,34 @@ def main():
     L = args.profile_level
     if L:
         net.profile_enable(L)
+    wait_s[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         flow = step(i)
+    t_own = time.perf_counter() - t0            # this rank's own steps, before it waits for the others
     fence()
     dt = time.perf_counter() - t0
     k_ms, k_empty_ms, k_n = net.profile_read() if L else (0.0, 0.0, 0)
     if L:
         net.profile_enable(0)
+    per_rank = [{"rank": 0, "pairs_per_s": round(args.steps * B / t_own, 3), "gather_wait_ms_per_step": 0.0}]
     if world > 1:
         t = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([args.steps * B / t_own, wait_s[0] / args.steps * 1e3], device=gdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "pairs_per_s": round(float(v[0]), 3), "gather_wait_ms_per_step": round(float(v[1]), 4)} for r, v in enumerate(allr)]
+    # level-1 launch of the same kernel family (395 MB: beyond the 256 MiB Infinity Cache), timed the same way in a few extra steps
+    l1 = None
+    if L == 3 and world == 1 and args.model == "piv" and args.size == 1024 and net.lowest_level == 1:
+        net.profile_enable(1)
+        for i in range(5):
+            step(i)
+        fence()
+        l1 = net.profile_read()
+        net.profile_enable(0)
 
     if rank == 0:
         pairs = args.steps * B * world
@@ -207,15 +256,10 @@ def main():
             t_k = k_ms / k_n * 1e-3                       # start/stop events attached to the dispatch itself
             t_pair = k_empty_ms / k_n * 1e-3              # plain hipEventRecord pair around the same launch (incl. marker cost)
             ach = alg / t_k / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_l3_warp_corr.json")
-            if os.path.exists(pmc) and B == 1 and S == 1024 and L == 3:
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            traffic, traffic_src = (counter_traffic("r02_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
+                                    else (None, "no counter pass for this workload"))
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "traffic": traffic, "kernel": f"warp_corr_kernel (level {L}: C={C}, stride {stride})",
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": f"warp_corr_kernel (level {L}: C={C}, stride {stride})",
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(t_k * 1e6, 2), "launches_timed": k_n,
                     "event_record_pair_us": round(t_pair * 1e6, 2),
                     "timer": "HIP start/stop events attached to the dispatch (hipExtLaunchKernelGGL) in every timed step, on the "
@@ -240,10 +284,19 @@ def main():
                           "layer_boundary_gb_per_pair": 16.57 if (args.model == 'piv' and S == 1024) else None,
                           "hbm_frac_of_8tbs": round(value / world * 16.57 / 8000.0, 4) if (args.model == 'piv' and S == 1024) else None},
         }
+        out["per_rank"] = per_rank
+        if l1 is not None and l1[2]:
+            alg1 = l3_algorithmic_bytes(B, S, S, 1, 64, 2)
+            t1 = l1[0] / l1[2] * 1e-3
+            tr1, src1 = counter_traffic("r02_pmc_l1_warp_corr.json") if B == 1 else (None, "no counter pass for this workload")
+            out["roofline_level1"] = {"bound": "hbm", "achieved": round(alg1 / t1 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                      "frac": round(alg1 / t1 / 8e12, 4), "traffic": tr1, "traffic_source": src1,
+                                      "kernel": "warp_corr_kernel (level 1: C=64, stride 2; 395 MB per launch, beyond the Infinity Cache)",
+                                      "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2]}
         if world == 1 and args.model == "piv" and S == 1024:
             out["roofline_batch8"] = l3_throughput_regime(dev)
         if not args.no_cpu_baseline and world == 1:
-            ref, cb = cpu_baseline(args.model, S, wts, i1c, i2c)
+            ref, cb = cpu_baseline(args.model, S, wts, i1c, i2c, runs=args.cpu_runs)
             out["cpu_baseline"] = cb
             err = float((flow[:1].cpu() - ref).abs().max())
             out["parity_vs_oracle_max_abs_px"] = round(err, 7)

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 // PMAX / WMAX = compile-time bounds on the 16-byte loads per thread for the patch / the weight slab.
 // (64-accumulator tiles with the small staging class fit 168 VGPRs: three workgroups per CU)
 template <int MT, int NT, int PMAX, int WMAX>
-__global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2) void conv_mfma2_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2) void conv_mfma2_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BN = NT * 32;
@@ -370,6 +370,13 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
     } else {
         const int ox = x0 + row;
         const bool interior = x0 + 32 <= p.Wo && y0 + TH <= p.Ho && n0 + BN <= p.cout_store;   // workgroup-uniform fast path
+        // all bias vectors of this lane first (the staging registers are dead by now): a load between two stores would wait for
+        // the store in front of it -- vmcnt counts loads and stores in one order -- and serialise the whole epilogue
+        f32x4 bias4[NT][4];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[n][g] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + n * 32 + 8 * g + 4 * hh);   // bias is padded to cout_pad
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = y0 + wave * MT + m;
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX == 3) ? 3 : 2
                     if (!pix_ok || (!interior && ch >= p.cout_store)) continue;
                     if (CONV2_ABL(4) && acc[m][n][0] != 12345.f) continue;
                     f32x4 v = {acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
-                    v += *reinterpret_cast<const f32x4 *>(p.bias + ch);
+                    v += bias4[n][g];
                     if (rrow) v += *reinterpret_cast<const f32x4 *>(rrow + ch);
                     if (p.lrelu) {
                         v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
@@ -621,6 +628,12 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
         wm = cdiv(taps * 2 * nt_ * 32, 256);
     };
     int pm, wm;
+    // 16-row tiles for the 64- and 32-channel layers of the fine levels: the weight slab and the patch halo a workgroup
+    // restages per K chunk are amortised over twice the pixels (same accumulator budget as the 8-row x 128-channel tile)
+    if (nt <= 2 && mt == 2 && (px_blocks1 / 4) * (p.cout_pad / (nt * 32)) >= 512 && !(PIV_KNOB(1) & 16)) {
+        need(4, nt, pm, wm);
+        if (pm <= 5 && wm <= (nt == 2 ? 5 : 3)) return nt == 2 ? launch_t2<4, 2, 5, 5>(p, st) : launch_t2<4, 1, 5, 3>(p, st);
+    }
     need(mt, nt, pm, wm);
     if ((pm > 3 || wm > 9) && mt == 2 && nt >= 3) { mt = 1; need(mt, nt, pm, wm); }   // keep the big-staging class under 256 VGPRs
     if (pm > 9 || wm > 13) return -1;      // not covered: caller falls back to v1

@@ -615,9 +615,12 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     const unsigned rem_off = tid < 256 ? tapo[(tid & 3) * NPOS + rem_pos] + 16u * rem_q : OOB;
     const float rem_w = tid < 256 ? tapw[(tid & 3) * NPOS + rem_pos] : 0.f;
 
-    float acc[4];
+    // Two fma chains per displacement, A over channels {0-15, 32-47, ...} and B over {16-31, 48-63, ...}, added once at the end:
+    // the summation order of the throughput kernel (v3: a lane half per 16-channel half of every 32-channel chunk), so the two
+    // kernels return the same bits and a pair's flow cannot depend on which of them its batch size selects.
+    float accA[4], accB[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 4; ++k) accA[k] = accB[k] = 0.f;
 
 #pragma unroll 1
     for (int c0 = 0; c0 < p.C; c0 += 64) {
@@ -679,15 +682,15 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
                         const int dy = d / 7, dx = d - dy * 7;
                         const int r = ppy + dy, cx = ppx + dx;
                         const unsigned sb = (unsigned)(r * TP + cx) * 256u | (unsigned)((((r & 3) << 2) | (cx & 3)) << 4);
-                        float s0 = 0.f;
+                        float s0 = (h & 1) ? accB[k] : accA[k];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(fb + (sb ^ (unsigned)(16 * (4 * h + q))));
                             s0 = fmaf(a[q][0], v0[0], s0); s0 = fmaf(a[q][1], v0[1], s0);
                             s0 = fmaf(a[q][2], v0[2], s0); s0 = fmaf(a[q][3], v0[3], s0);
                         }
-                        acc[k] += s0;
-                        asm volatile("" : "+v"(acc[k]));
+                        asm volatile("" : "+v"(s0));
+                        if (h & 1) accB[k] = s0; else accA[k] = s0;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     for (int k = 0; k < 4; ++k) {
         const int d = grp + 16 * k;
         if (k < 3 || grp == 0) {
-            float v = acc[k] / cf;
+            float v = (accA[k] + accB[k]) / cf;
             if (p.leaky) v = lrelu01(v);
             ost[lane * OUTC + d] = v;
         }

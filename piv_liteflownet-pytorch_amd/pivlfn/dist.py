@@ -48,6 +48,8 @@ def gather_flows(local: torch.Tensor, n_total: int, group=None, async_op: bool =
     lo, hi = shard_bounds(n_total, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank} holds {local.shape[0]} flows, its shard is [{lo},{hi})")
+    if dist.get_backend(group) != "nccl" and local.is_cuda:
+        local = local.cpu()                    # gloo rehearsals on a GPU box: the collective runs on host copies
     tail = tuple(local.shape[1:])
     send = local.contiguous()
     if send.shape[0] != per:

@@ -81,3 +81,57 @@ def test_two_rank_gloo_run_sharded(n_pairs, batch):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _seq_worker(rank, world, port, n_frames, chunk, outdir, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pivlfn import synth
+    from pivlfn.sequence import run_sequence
+    seq = synth.ParticleSequence(32, 48, seed=3, device="cpu")
+    asked = []
+
+    def frames(f0, f1):
+        asked.extend(range(f0, f1))
+        return seq.frames(f0, f1)
+
+    def stub_estimate(net, a, b, tensor=True):          # stands in for pivlfn.estimate: [n,3,H,W] x2 -> [n,2,H,W]
+        return torch.stack([b[:, 0] - a[:, 0], a[:, 0] + 2.0 * b[:, 0]], 1)
+
+    st = run_sequence(None, frames, n_frames, chunk, torch.device("cpu"), write_dir=outdir, rank=rank, world=world,
+                      estimate_fn=stub_estimate)
+    q.put((rank, st["pairs_this_rank"], st["flows_emitted"], asked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,chunk", [(8, 3), (6, 4), (3, 2)])
+def test_two_rank_gloo_sequence(tmp_path, n_frames, chunk):
+    """pivlfn.sequence.run_sequence (BASELINE config #4's loop) on two gloo ranks with a stub estimate: contiguous shards, one
+    halo frame per rank, every frame rendered once per rank, rank 0 writes every pair's .flo exactly once."""
+    import numpy as np
+    from pivlfn import synth
+    from pivlfn.flo import read_flow
+    from pivlfn.sequence import flow_file_name
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    out = str(tmp_path / "flow")
+    procs = [ctx.Process(target=_seq_worker, args=(r, 2, port, n_frames, chunk, out, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_pairs = n_frames - 1
+    assert res[0][1] + res[1][1] == n_pairs and res[0][2] == n_pairs and res[1][2] == 0
+    for r in range(2):
+        lo, hi = shard_bounds(n_pairs, r, 2)
+        assert res[r][3] == (list(range(lo, hi + 1)) if hi > lo else [])       # its shard's frames + the halo, each once, in order
+    fr = synth.ParticleSequence(32, 48, seed=3, device="cpu").frames(0, n_frames).to(torch.float32) / 255.0
+    assert sorted(os.listdir(out)) == [flow_file_name(k) for k in range(n_pairs)]
+    for k in range(n_pairs):
+        want = torch.stack([fr[k + 1] - fr[k], fr[k] + 2.0 * fr[k + 1]], -1).numpy()
+        assert np.array_equal(read_flow(os.path.join(out, flow_file_name(k))), want)

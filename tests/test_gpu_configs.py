@@ -1,0 +1,265 @@
+"""GPU: every workload of BASELINE.json `configs` at its own size (or, for the 8-GPU ones, the per-GPU share and a miniature
+of the multi-rank control flow), checked against the oracle / against size-independent properties.
+
+  configs[0]  run.py --model hui on two 256x256 particle images                    -> test_config0_*
+  configs[1]  PIV forward, batch 1, 1024x1024 fp32                                 -> tests/test_gpu_net.py::test_full_size_1024_properties, bench.py
+  configs[2]  batch 32 x 512x512                                                   -> test_config2_*
+  configs[3]  10 000-frame 1024x1024 sequence sharded over 8 GPUs                  -> test_config3_* (9 frames, 1 rank + 2-rank gloo rehearsal)
+  configs[4]  fp16 activations / fp32 accumulate, batch 64 x 1024x1024 over 8 GPUs -> test_config4_* (the per-GPU share: 8 x 1024x1024)
+"""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import pivlfn
+import pivlfn_oracle as orc
+from pivlfn import synth
+from pivlfn.flo import read_flow
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+E2E_MAX, E2E_MEAN = 1e-4, 1e-5          # fp32 end-to-end tolerance, relative to max(1, max|flow|)
+
+
+def _check(got, want, what):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(1.0, np.abs(want).max())
+    err = np.abs(got - want)
+    assert err.max() <= E2E_MAX * scale, f"{what}: max-abs {err.max():.3e} at flow scale {scale:.2f}"
+    assert err.mean() <= E2E_MEAN * scale, f"{what}: mean-abs {err.mean():.3e}"
+
+
+# ---- configs[0] ---------------------------------------------------------------------------------------------------
+def test_config0_run_py_hui_256_pair(tmp_path, dev):
+    """`run.py --model hui -p` on 256x256 pairs: one synthetic particle pair and the reference's own demo pair
+    (tests/golden/DNS_turbulence_img{1,2}.tif, grey TIFFs) -> .flo files against the oracle's estimate() on the CPU."""
+    import PIL.Image
+    import run as runpy
+    d = tmp_path / "pairs"
+    d.mkdir()
+    a, b, _ = synth.particle_pair(256, 256, 4242)
+    PIL.Image.fromarray(a).save(str(d / "synthetic_img1.png"))
+    PIL.Image.fromarray(b).save(str(d / "synthetic_img2.png"))
+    for k in (1, 2):
+        with open(os.path.join(GOLDEN, f"DNS_turbulence_img{k}.tif"), "rb") as src, open(str(d / f"DNS_turbulence_img{k}.tif"), "wb") as dst:
+            dst.write(src.read())
+    out = tmp_path / "out"
+    assert runpy.main(["--model", "hui", "-p", "-i", str(d), "-o", str(out), "--batch", "1"]) == 2
+    flodir = out / "hui-synthetic" / "pairs" / "flow"
+    assert sorted(os.listdir(flodir)) == ["DNS_turbulence_out.flo", "synthetic_out.flo"]
+    onet = orc.make_net("hui", synth.generate_weights("hui", 0), corr="c")
+    for name, ext in (("synthetic", "png"), ("DNS_turbulence", "tif")):
+        ims = [np.asarray(PIL.Image.open(str(d / f"{name}_img{k}.{ext}")).convert("RGB"), dtype=np.uint8) for k in (1, 2)]
+        x = [torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1))).float().div_(255.0)[None] for im in ims]
+        with torch.no_grad():
+            want = orc.estimate(onet, x[0], x[1], tensor=False)
+        got = read_flow(str(flodir / f"{name}_out.flo"))
+        assert got.shape == (256, 256, 2)
+        _check(got, want, f"run.py hui {name}")
+        assert np.abs(want).max() > 0.5                             # the pair does carry a flow
+
+
+def test_config0_run_py_brightness_contrast(tmp_path, dev):
+    """`run.py -b 1.0 1.5 -c 0.75` (reference main(), run.py:100-134): one .flo per consecutive pair and combination, named
+    <prefix>_<BBB>_<CCC>_<suffix>_out.flo, equal to Inference.parser on PIL images enhanced the way the reference does."""
+    import PIL.Image
+    import PIL.ImageEnhance
+    import run as runpy
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    frames = []
+    for k in range(3):
+        a, _, _ = synth.particle_pair(64, 96, 900 + k)
+        frames.append(a)
+        PIL.Image.fromarray(a).save(str(seq / f"cam_{k:04d}.png"))
+    out = tmp_path / "out"
+    n = runpy.main(["-m", "piv", "-i", str(seq), "-o", str(out), "-b", "1.0", "1.5", "-c", "0.75", "--batch", "2"])
+    assert n == 2 * 2
+    flodir = out / "piv-synthetic" / "seq" / "flow"
+    assert sorted(os.listdir(flodir)) == ["cam_100_075_0000_out.flo", "cam_100_075_0001_out.flo",
+                                          "cam_150_075_0000_out.flo", "cam_150_075_0001_out.flo"]
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+
+    def enhanced(arr, b, c):
+        im = PIL.Image.fromarray(arr).convert("RGB")
+        return PIL.ImageEnhance.Contrast(PIL.ImageEnhance.Brightness(im).enhance(b)).enhance(c)
+    for b in (1.0, 1.5):
+        for k in range(2):
+            want = pivlfn.Inference.parser(net, enhanced(frames[k], b, 0.75), enhanced(frames[k + 1], b, 0.75), device=dev)
+            got = read_flow(str(flodir / f"cam_{int(b * 100):03d}_075_{k:04d}_out.flo"))
+            assert np.array_equal(got, want), (b, k)
+
+
+# ---- configs[2] ---------------------------------------------------------------------------------------------------
+def test_config2_batch32_512(dev):
+    """32 pairs of 512x512 in one forward: every pair equals its single-pair flow bit for bit (nothing in the path may depend
+    on the batch mates: per-image split-K rule, one summation order in both warp+correlation kernels), and two of them are
+    checked against the oracle on the CPU."""
+    B, S = 32, 512
+    a, b = synth.particle_batch(B, S, S, seed=2024)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    lib_bytes = pivlfn._lib.load().pivlfn_workspace_bytes(net._native(), B, S, S)
+    full = net(i1, i2)
+    assert net._ws.numel() == lib_bytes                           # the workspace query is what the forward was given
+    assert tuple(full.shape) == (B, 2, S, S) and torch.isfinite(full).all()
+    for k in range(B):
+        one = net(i1[k:k + 1], i2[k:k + 1])
+        assert torch.equal(one[0], full[k]), f"pair {k} depends on its batch mates"
+    onet = orc.make_net("piv", synth.generate_weights("piv", 0), corr="c")
+    for k in (0, 17):
+        with torch.no_grad():
+            want = onet.forward(torch.from_numpy(a[k:k + 1]), torch.from_numpy(b[k:k + 1])).numpy()
+        _check(full[k:k + 1].cpu().numpy(), want, f"batch-32 pair {k}")
+
+
+# ---- configs[3] ---------------------------------------------------------------------------------------------------
+def _sequence_reference(dev, n_frames, S, seed):
+    """estimate() pair by pair on the frames run_sequence renders."""
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    fr = synth.ParticleSequence(S, S, seed=seed, device=dev).frames(0, n_frames)
+    x = fr.to(torch.float32).div_(255.0)[:, None].expand(-1, 3, -1, -1).contiguous()
+    return net, [pivlfn.estimate(net, x[k:k + 1], x[k + 1:k + 2], tensor=False) for k in range(n_frames - 1)]
+
+
+def test_config3_sequence_miniature_one_rank(tmp_path, dev):
+    """9 frames of 1024x1024, chunks of 4 pairs, one rank: 8 .flo files, bit-equal to estimate() on each pair."""
+    from pivlfn.sequence import flow_file_name, run_sequence
+    n_frames, S = 9, 1024
+    net, want = _sequence_reference(dev, n_frames, S, seed=99)
+    seq = synth.ParticleSequence(S, S, seed=99, device=dev)
+    st = run_sequence(net, seq.frames, n_frames, 4, dev, write_dir=str(tmp_path / "flow"))
+    assert st["pairs_total"] == 8 and st["flows_emitted"] == 8
+    assert sorted(os.listdir(tmp_path / "flow")) == [flow_file_name(k) for k in range(8)]
+    for k in range(8):
+        got = read_flow(str(tmp_path / "flow" / flow_file_name(k)))
+        assert got.shape == (S, S, 2) and np.array_equal(got, want[k]), f"pair {k}"
+    assert np.abs(want[0]).max() > 1.0
+
+
+def _run_children(cmd_for_rank, world, env_extra, timeout=900):
+    """Fresh child processes, one per rank (never an exec of this GPU-initialised process)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+        procs.append(subprocess.Popen(cmd_for_rank(r), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, f"child failed rc={rc}\nstdout:\n{o[-2000:]}\nstderr:\n{e[-4000:]}"
+    return outs
+
+
+def test_config3_sequence_two_rank_rehearsal(tmp_path, dev):
+    """The 2-rank control flow of config #4 on one GPU (gloo instead of RCCL, both ranks on device 0): contiguous shards, halo
+    frame, per-chunk all-gather, rank 0 writes -- the same .flo set, bit for bit, as estimate() pair by pair."""
+    from pivlfn.sequence import flow_file_name
+    n_frames, S = 8, 512                                            # 7 pairs: shards of 4 and 3, chunk 3 -> a short last chunk
+    outdir = tmp_path / "flow2"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "sequence_run.py"), "--frames", str(n_frames), "--size", str(S), "--chunk", "3",
+           "--write", str(outdir), "--seed", "7"]
+    outs = _run_children(lambda r: cmd, 2, {"PIVLFN_BENCH_BACKEND": "gloo"})
+    line = json.loads([ln for ln in outs[0][1].splitlines() if ln.startswith("{")][-1])
+    assert line["flo_files_written"] == 7
+    _, want = _sequence_reference(dev, n_frames, S, seed=7)
+    assert sorted(os.listdir(outdir)) == [flow_file_name(k) for k in range(7)]
+    for k in range(7):
+        assert np.array_equal(read_flow(str(outdir / flow_file_name(k))), want[k]), f"pair {k}"
+
+
+def test_bench_py_two_rank_rehearsal(dev):
+    """bench.py's N>1 path (barrier, max over ranks, async gather, one JSON line from rank 0) rehearsed with gloo as two fresh
+    child processes on this one GPU, at a small size."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256", "--no-cpu-baseline"]
+    outs = _run_children(lambda r: cmd, 2, {"PIVLFN_BENCH_BACKEND": "gloo"})
+    lines = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][1].splitlines() if ln.startswith("{")]      # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["unit"] == "image-pairs/s"
+    assert j["value"] > 0 and len(j["per_rank"]) == 2
+    assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01                  # value = all ranks' pairs / max time
+
+
+# ---- configs[4] ---------------------------------------------------------------------------------------------------
+def test_config4_fp16_batch8_1024(dev):
+    """The per-GPU share of config #5 (64 x 1024x1024 over 8 GPUs = 8 per GPU) in the fp16-multiplicand mode: finite, the
+    workspace query is honoured, and every pair stays within the stated end-point-error bound of the fp32 mode."""
+    B, S = 8, 1024
+    a, b = synth.particle_batch(B, S, S, seed=5150)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    f32 = net(i1, i2)
+    net.precision = "fp16"
+    need = pivlfn._lib.load().pivlfn_workspace_bytes(net._native(), B, S, S)
+    f16 = net(i1, i2)
+    assert net._ws.numel() >= need and torch.isfinite(f16).all() and tuple(f16.shape) == (B, 2, S, S)
+    epe = torch.sqrt(((f16 - f32) ** 2).sum(1))                    # [B,H,W]
+    per_pair = epe.flatten(1).mean(1).cpu().numpy()
+    print("fp16 mode, 8 x 1024x1024: mean EPE per pair vs fp32 mode:", np.round(per_pair, 5), "max", float(epe.max()))
+    assert (per_pair <= 0.05).all() and float(epe.max()) <= 0.5
+    assert not torch.equal(f16, f32)
+    one = net(i1[3:4], i2[3:4])
+    assert torch.equal(one[0], f16[3])                              # batch-independent in this mode too
+    # a workspace that is too small is refused, not overrun
+    lib = pivlfn._lib.load()
+    small = torch.empty(1024, dtype=torch.uint8, device=dev)
+    out = torch.empty(B, 2, S, S, device=dev)
+    rc = lib.pivlfn_forward(net._native(), i1.data_ptr(), i2.data_ptr(), out.data_ptr(), None, B, S, S, small.data_ptr(), small.numel(),
+                            torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 3 and b"workspace" in lib.pivlfn_last_error()
+
+
+# ---- boundary: re-entrancy ------------------------------------------------------------------------------------------
+def test_two_nets_two_threads_two_streams(dev):
+    """The library keeps no process-global mutable state: two handles driven from two threads on two streams give the flows a
+    single-threaded run gives, bit for bit (include/pivlfn.h; SURVEY.md section 8(b) 'Threading / streams')."""
+    wts = synth.generate_weights("piv", 0)
+    nets = [pivlfn.piv_liteflownet(wts).to(dev).eval() for _ in range(2)]
+    pairs = []
+    for t in range(2):
+        a, b = synth.particle_batch(1, 256, 320, seed=60 + t)
+        pairs.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)))
+    want = [nets[0](*pairs[t]).clone() for t in range(2)]
+    torch.cuda.synchronize()
+    got = [None, None]
+    errs = []
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream(dev)
+            with torch.cuda.stream(s):
+                for _ in range(6):
+                    f = nets[t](*pairs[t])
+                s.synchronize()
+            got[t] = f
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(2):
+        assert torch.equal(got[t], want[t])

@@ -96,17 +96,25 @@ def bench_wc_ablate(args):
         lib.pivlfn_tune(2, 0)
 
 
-CONV_SHAPES = [
+def _level_layers(L, n):
+    """Every dense conv of level L's Matching / Subpixel / Regularization stacks (src/models.py:154-163, 197-207, 236-267) at
+    the level's resolution n x n; staged input channels (multiples of 4) as pivlfn_forward stages them."""
+    return [(f"L{L} M.0 49->128", 128, 56, 3, 1, n, 1), (f"L{L} M.2 128->64", 64, 128, 3, 1, n, 1), (f"L{L} M.4 64->32", 32, 64, 3, 1, n, 1),
+            (f"L{L} S.0 130->128", 128, 136, 3, 1, n, 1), (f"L{L} S.2 128->64", 64, 128, 3, 1, n, 1), (f"L{L} S.4 64->32", 32, 64, 3, 1, n, 1),
+            (f"L{L} R.0 131->128", 128, 132, 3, 1, n, 1), (f"L{L} R.2 128->128", 128, 128, 3, 1, n, 1), (f"L{L} R.4 128->64", 64, 128, 3, 1, n, 1),
+            (f"L{L} R.6 64->64", 64, 64, 3, 1, n, 1), (f"L{L} R.8 64->32", 32, 64, 3, 1, n, 1), (f"L{L} R.10 32->32", 32, 32, 3, 1, n, 1)]
+
+
+CONV_SHAPES = _level_layers(1, 1024) + _level_layers(2, 512) + [
     # name, cout, cin, k, stride, H(=W) at the 1024x1024 PIV forward, batch multiplier
-    ("L1 R.conv_R.2 128->128", 128, 128, 3, 1, 1024, 1), ("L1 S.conv_S.0 130->128", 128, 136, 3, 1, 1024, 1),
-    ("L1 M.conv_M.0 49->128", 128, 56, 3, 1, 1024, 1), ("L1 conv 128->64", 64, 128, 3, 1, 1024, 1),
-    ("L1 conv 64->64", 64, 64, 3, 1, 1024, 1), ("L1 conv 64->32", 32, 64, 3, 1, 1024, 1), ("L1 conv 32->32", 32, 32, 3, 1, 1024, 1),
-    ("L2 conv 128->128", 128, 128, 3, 1, 512, 1), ("L3 conv 128->128", 128, 128, 3, 1, 256, 1),
+    ("L3 conv 128->128", 128, 128, 3, 1, 256, 1),
     ("L4 conv 128->128", 128, 128, 3, 1, 128, 1), ("L5 conv 128->128", 128, 128, 3, 1, 64, 1), ("L6 conv 128->128", 128, 128, 3, 1, 32, 1),
     ("L6 S.conv_S.0 386->128", 128, 392, 3, 1, 32, 1), ("L5 S.conv_S.0 258->128", 128, 264, 3, 1, 64, 1),
     ("NetC.conv1 7x7 3->32", 32, 4, 7, 1, 1024, 2), ("NetC.conv2.0 s2 32->32", 32, 32, 3, 2, 1024, 2),
-    ("NetC.conv3.0 s2 32->64", 64, 32, 3, 2, 512, 2), ("NetC.conv5.0 s2 96->128", 128, 96, 3, 2, 128, 2),
-    ("L1 moduleFeat 1x1 32->128", 128, 32, 1, 1, 1024, 1), ("L1 dist 7x1 32->49", 49, 32, (7, 1), 1, 1024, 1),
+    ("NetC.conv2.2 32->32 @512", 32, 32, 3, 1, 512, 2), ("NetC.conv3.0 s2 32->64", 64, 32, 3, 2, 512, 2),
+    ("NetC.conv3.2 64->64 @256", 64, 64, 3, 1, 256, 2), ("NetC.conv5.0 s2 96->128", 128, 96, 3, 2, 128, 2),
+    ("L1 moduleFeat 1x1 32->128", 128, 32, 1, 1, 1024, 1), ("L1 NetC_ext 1x1 32->64", 64, 32, 1, 1, 1024, 2),
+    ("L1 dist 7x1 32->49", 49, 32, (7, 1), 1, 1024, 1),
     ("L1 dist 1x7 49->49", 49, 52, (1, 7), 1, 1024, 1),
 ]
 

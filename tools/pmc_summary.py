@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-launch HBM traffic of the level-L warp+correlation launch from the rocprofv3 --pmc passes of tools/pmc_l3.sh.
+
+FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts a 128-byte request of a 16-byte-per-lane read as 64
+bytes (MI355X_MICROARCH.md, section HBM): it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  The JSON carries
+the hash of the kernel sources it was measured on: bench.py quotes `traffic` only when that hash matches the working tree."""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir, level = sys.argv[1], int(sys.argv[2])
+C, n, s = {1: (64, 1024, 2), 2: (64, 512, 2), 3: (64, 256, 2)}[level]
+tiles = (n // s // 8) ** 2
+
+
+def counters(tag):
+    vals = {}
+    for path in glob.glob(os.path.join(out_dir, tag, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if "warp_corr" not in r["Kernel_Name"]:
+                continue
+            wg = int(r["Workgroup_Size"]) if "Workgroup_Size" in r else int(r["Workgroup_Size_X"])
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
+            if grid // wg != tiles:
+                continue
+            vals.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
+            vals[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+            vals["_kernel"] = r["Kernel_Name"]
+    return vals
+
+
+res = {}
+for tag in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
+    res.update(counters(tag))
+mean = lambda d: sum(d.values()) / max(1, len(d))        # noqa: E731
+fetch_kb, write_kb = mean(res.get("FETCH_SIZE", {})), mean(res.get("WRITE_SIZE", {}))
+h = hashlib.sha256()
+for rel in ("piv_liteflownet-pytorch_amd/csrc/warp_corr.hip", "piv_liteflownet-pytorch_amd/csrc/common.h"):
+    h.update(open(os.path.join(ROOT, rel), "rb").read())
+no = n // s
+alg = 4 * (C * no * no + C * n * n + 2 * n * n + 49 * no * no)
+print(json.dumps({
+    "kernel": f"{res.get('_kernel', '?')} (level {level} of PIV 1024x1024 B=1: C={C}, stride {s}, {tiles} workgroups)",
+    "launches_averaged": len(res.get("FETCH_SIZE", {})),
+    "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+    "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane reads; MI355X_MICROARCH.md section HBM); WRITE_SIZE exact",
+    "hbm_bytes_per_launch": int(round((2 * fetch_kb + write_kb) * 1024)),
+    "algorithmic_bytes_per_launch": alg,
+    "TCC_HIT_sum": mean(res.get("TCC_HIT_sum", {})), "TCC_MISS_sum": mean(res.get("TCC_MISS_sum", {})),
+    "kernel_source_sha256_16": h.hexdigest()[:16],
+    "passes": "three separate rocprofv3 --pmc runs of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0` (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum), tools/pmc_l3.sh",
+}, indent=1))
