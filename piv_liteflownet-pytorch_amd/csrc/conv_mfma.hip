@@ -593,6 +593,11 @@ static int launch_conv_k1(const ConvParams &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
+// (Measured and dropped in round 2: a dedicated streaming kernel for the HBM-bound 1x1 layers -- NetC_ext 32 -> 64, moduleFeat
+// 32 -> 128 -- with the whole weight matrix resident in LDS, operands read straight from global memory one pixel run ahead and no
+// barriers: 193.7 vs 195.8 us (moduleFeat, level 1) and 216.7 vs 235.3 us (NetC_ext) against this kernel's 16-row tiles, and no
+// change of the step time.  Both run at ~3.5 TB/s of a 4:1 write-heavy stream; tools/bench_ops.py conv --filter 1x1.)
+
 // Tile choice for v2.  Staging loads per thread: patch = PH*PW*2/256, slab = taps*2*BN/256 (16-byte each).
 static int launch_conv2(const ConvParams &p_in, hipStream_t st)
 {
@@ -628,11 +633,12 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
         wm = cdiv(taps * 2 * nt_ * 32, 256);
     };
     int pm, wm;
-    // 16-row tiles for the 64- and 32-channel layers of the fine levels: the weight slab and the patch halo a workgroup
-    // restages per K chunk are amortised over twice the pixels (same accumulator budget as the 8-row x 128-channel tile)
-    if (nt <= 2 && mt == 2 && (px_blocks1 / 4) * (p.cout_pad / (nt * 32)) >= 512 && !(PIV_KNOB(1) & 16)) {
+    // 16-row tiles for the 64-channel layers of the fine levels: the weight slab and the patch halo a workgroup restages per
+    // K chunk are amortised over twice the pixels (same accumulator budget as the 8-row x 128-channel tile).  Measured at level 1:
+    // 128->64 113 -> 129 TFLOP/s, 64->64 104 -> 119; the 32-channel layers LOSE with 16 rows (116 -> 96) and keep 8.
+    if (nt == 2 && mt == 2 && (px_blocks1 / 4) * (p.cout_pad / 64) >= 512 && !(PIV_KNOB(1) & 16)) {
         need(4, nt, pm, wm);
-        if (pm <= 5 && wm <= (nt == 2 ? 5 : 3)) return nt == 2 ? launch_t2<4, 2, 5, 5>(p, st) : launch_t2<4, 1, 5, 3>(p, st);
+        if (pm <= 5 && wm <= 5) return launch_t2<4, 2, 5, 5>(p, st);
     }
     need(mt, nt, pm, wm);
     if ((pm > 3 || wm > 9) && mt == 2 && nt >= 3) { mt = 1; need(mt, nt, pm, wm); }   // keep the big-staging class under 256 VGPRs

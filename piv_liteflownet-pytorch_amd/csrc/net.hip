@@ -63,7 +63,7 @@ struct pivlfn_net {
     std::vector<void *> allocs;
     // side stream for the flow-independent 1x1 convs (NetC_ext, moduleFeat): they overlap the latency-bound coarse levels
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // measurement hooks
     int prof_level = 0;
     std::vector<hipEvent_t> ev;
@@ -192,7 +192,7 @@ int net_destroy(pivlfn_net *net)
     if (!net) return PIVLFN_OK;
     for (void *p : net->allocs) (void)hipFree(p);
     for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
-    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    for (hipEvent_t e : net->ev_fork) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : net->ev_join) if (e) (void)hipEventDestroy(e);
     if (net->side) (void)hipStreamDestroy(net->side);
     delete net;
@@ -321,13 +321,14 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
         lw.by = by->data[0];
     }
 #undef TRY
-    if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess) {
-        set_error("create: side stream / event creation failed");
+    if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess) {
+        set_error("create: side stream creation failed");
         net_destroy(net);
         return PIVLFN_ERR_HIP;
     }
     for (int L = lowest; L <= 6; ++L)
-        if (hipEventCreateWithFlags(&net->ev_join[L], hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&net->ev_join[L], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&net->ev_fork[L], hipEventDisableTiming) != hipSuccess) {
             set_error("create: event creation failed");
             net_destroy(net);
             return PIVLFN_ERR_HIP;
@@ -558,34 +559,43 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     // mean subtraction + layout change (:321-323), image pyramid (:336-343)
     RUN(launch_prep_images(img1, img2, bf.img[1], B, H, W, net->mean, st));
     for (int L = 2; L <= 6; ++L) RUN(launch_resize_nhwc4(bf.img[L - 1], bf.img[L], N2, h[L - 1], w[L - 1], h[L], w[L], st));
+    // Flow-independent 1x1 convs on the side stream: NetC_ext (:353-355) for levels <= 2 and Regularization.moduleFeat (:227-232,
+    // applied at :280) for levels < 5.  Each level's share is issued as soon as NetC has produced that level's feature map, so the
+    // HBM-bound 1x1 work overlaps the rest of NetC (large MFMA-bound grids) instead of the latency-bound chains of tiny kernels of
+    // levels 6-4, which lose most when CUs are taken away from them (the level-5 warp+correlation, a whole CU per tile, waited
+    // 80 us for a free CU behind the level-1 share).
+    const hipStream_t side = (PIV_KNOB(1) & 2048) ? st : net->side;        // tools A/B: everything on one stream
+    const bool side_early = !(PIV_KNOB(1) & 4096);                         // tools A/B: 4096 = round-1 order (all of it after NetC)
+    auto side_level = [&](int L) -> int {
+        if (L < net->lowest || L > 4) return PIVLFN_OK;
+        if (side != st) {
+            PIV_CHECK_HIP(hipEventRecord(net->ev_fork[L], st));
+            PIV_CHECK_HIP(hipStreamWaitEvent(side, net->ev_fork[L], 0));
+        }
+        RUN(conv(net->lv[L].feat, {{bf.feat[L], C_FEAT[L], C_FEAT[L]}}, bf.featR[L], 128, 128, nullptr, 0, 1, B, h[L], w[L], 1, 0, 0, side));
+        if (L <= 2)
+            RUN(conv(net->ext[L], {{bf.feat[L], 32, 32}}, bf.ext[L], 64, 64, nullptr, 0, 1, N2, h[L], w[L], 1, 0, 0, side));
+        PIV_CHECK_HIP(hipEventRecord(net->ev_join[L], side));
+        return PIVLFN_OK;
+    };
     // NetC on both frames as one batch of 2B (:325-326, Features.forward :108-116)
     const ConvW *nc = net->netc;
     RUN(conv(nc[0], {{bf.img[1], 4, 4}}, bf.feat[1], 32, 32, nullptr, 0, 1, N2, h[1], w[1], 1, 3, 3, st));
+    if (side_early) RUN(side_level(1));
     RUN(conv(nc[1], {{bf.feat[1], 32, 32}}, bf.sa, 32, 32, nullptr, 0, 1, N2, h[1], w[1], 2, 1, 1, st));
     RUN(conv(nc[2], {{bf.sa, 32, 32}}, bf.sb, 32, 32, nullptr, 0, 1, N2, h[2], w[2], 1, 1, 1, st));
     RUN(conv(nc[3], {{bf.sb, 32, 32}}, bf.feat[2], 32, 32, nullptr, 0, 1, N2, h[2], w[2], 1, 1, 1, st));
+    if (side_early) RUN(side_level(2));
     RUN(conv(nc[4], {{bf.feat[2], 32, 32}}, bf.sa, 64, 64, nullptr, 0, 1, N2, h[2], w[2], 2, 1, 1, st));
     RUN(conv(nc[5], {{bf.sa, 64, 64}}, bf.feat[3], 64, 64, nullptr, 0, 1, N2, h[3], w[3], 1, 1, 1, st));
+    if (side_early) RUN(side_level(3));
     RUN(conv(nc[6], {{bf.feat[3], 64, 64}}, bf.sa, 96, 96, nullptr, 0, 1, N2, h[3], w[3], 2, 1, 1, st));
     RUN(conv(nc[7], {{bf.sa, 96, 96}}, bf.feat[4], 96, 96, nullptr, 0, 1, N2, h[4], w[4], 1, 1, 1, st));
+    if (side_early) RUN(side_level(4));
     RUN(conv(nc[8], {{bf.feat[4], 96, 96}}, bf.feat[5], 128, 128, nullptr, 0, 1, N2, h[4], w[4], 2, 1, 1, st));
     RUN(conv(nc[9], {{bf.feat[5], 128, 128}}, bf.feat[6], 192, 192, nullptr, 0, 1, N2, h[5], w[5], 2, 1, 1, st));
-    // Flow-independent 1x1 convs on the side stream, finest level last so the coarse levels get theirs first:
-    // NetC_ext (:353-355) for levels <= 2 and Regularization.moduleFeat (:227-232, applied at :280) for levels < 5.
-    // (Holding level 1's share back until the level-3 warp+correlation has been issued was measured: that launch drops from
-    // 14.6 to 13.4 us -- the 1 GB the side stream writes no longer evicts the level-3 features from the Infinity Cache -- but
-    // the step grows by 0.2 ms because the HBM-bound 1x1 convs then compete with the MFMA-bound stacks.  Not kept.)
-    auto side_level = [&](int L) -> int {
-        if (L < 5)
-            RUN(conv(net->lv[L].feat, {{bf.feat[L], C_FEAT[L], C_FEAT[L]}}, bf.featR[L], 128, 128, nullptr, 0, 1, B, h[L], w[L], 1, 0, 0, net->side));
-        if (L <= 2)
-            RUN(conv(net->ext[L], {{bf.feat[L], 32, 32}}, bf.ext[L], 64, 64, nullptr, 0, 1, N2, h[L], w[L], 1, 0, 0, net->side));
-        PIV_CHECK_HIP(hipEventRecord(net->ev_join[L], net->side));
-        return PIVLFN_OK;
-    };
-    PIV_CHECK_HIP(hipEventRecord(net->ev_fork, st));
-    PIV_CHECK_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
-    for (int L = 4; L >= net->lowest; --L) RUN(side_level(L));
+    if (!side_early)
+        for (int L = 4; L >= net->lowest; --L) RUN(side_level(L));
 
     float *prev = nullptr, *cur = bf.flowA;
     size_t lvoff = 0;

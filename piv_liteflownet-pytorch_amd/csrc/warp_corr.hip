@@ -260,6 +260,31 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rs, unsigned off)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
 }
 
+// Bilinear blend of one 16-byte quad from its four taps: w0*x0, then three fused multiply-adds in tap order.  Written with
+// explicit fmaf so that every kernel rounds the same way (left to the compiler, a*b + c*d may fuse either product).
+__device__ __forceinline__ f32x4 blend_taps(float w0, float w1, float w2, float w3, f32x4 x0, f32x4 x1, f32x4 x2, f32x4 x3)
+{
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaf(w3, x3[e], fmaf(w2, x2[e], fmaf(w1, x1[e], __fmul_rn(w0, x0[e]))));
+    return v;
+}
+// The same blend for the four left-over tile positions 192..195, whose taps the first kernels spread over four lanes and add
+// as a pairwise tree: (w0*x0 + w1*x1) + (w2*x2 + w3*x3), every operation rounded.
+__device__ __forceinline__ f32x4 blend_taps_tree(float w0, float w1, float w2, float w3, f32x4 x0, f32x4 x1, f32x4 x2, f32x4 x3)
+{
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        v[e] = __fadd_rn(__fadd_rn(__fmul_rn(w0, x0[e]), __fmul_rn(w1, x1[e])), __fadd_rn(__fmul_rn(w2, x2[e]), __fmul_rn(w3, x3[e])));
+    return v;
+}
+
+// sum / (float)C of the reference kernel (src/correlation.py:98-100).  For a power-of-two C (64 and 128 here) the product with
+// the exact reciprocal is the same number and one instruction instead of a division sequence; `inv` = 0 otherwise.
+__device__ __forceinline__ float mean_over_c(float sum, float cf, float inv) { return inv != 0.f ? sum * inv : sum / cf; }
+__device__ __forceinline__ float pow2_reciprocal(int C) { return (C & (C - 1)) == 0 ? 1.f / (float)C : 0.f; }
+
 // R2 layouts (see WC3_DOTS_R2): with lane = (column ppx, row pair rp) the 16-lane groups of a ds_read_b128 span four row pairs,
 // so the quad swizzle of the warped tile keys on (r>>1)&3 instead of r&3, and the f1 tile's on the row-pair's upper bit.
 template <bool R2>
@@ -363,15 +388,17 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
     do {                                                                                          \
         _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                           \
             const int pos = pos0 + 64 * u;                                                        \
-            f32x4 v = tapw[pos] * X[u][0];                                                        \
-            _Pragma("unroll") for (int k = 1; k < NT; ++k) v += tapw[k * NPOS + pos] * X[u][k];   \
+            f32x4 v;                                                                              \
+            if (NT == 4) v = blend_taps(tapw[pos], tapw[NPOS + pos], tapw[2 * NPOS + pos], tapw[3 * NPOS + pos], X[u][0], X[u][NT > 1 ? 1 : 0], X[u][NT > 2 ? 2 : 0], X[u][NT > 3 ? 3 : 0]); \
+            else v = tapw[pos] * X[u][0];                                                         \
             *reinterpret_cast<f32x4 *>(F2W + pos * PP + 4 * (q8 ^ swz_sel<R2>(pos))) = v;         \
         }                                                                                         \
         if (grp < 2) {      /* waves 0,1: the 32 left-over items, one tap per lane, summed over each lane quad */ \
-            f32x4 v = rem_w * XR;                                                                 \
+            f32x4 v;                                                                              \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                       \
-                v[e] += __shfl_xor(v[e], 1);                                                      \
-                v[e] += __shfl_xor(v[e], 2);                                                      \
+                v[e] = __fmul_rn(rem_w, XR[e]);                                                   \
+                v[e] = __fadd_rn(v[e], __shfl_xor(v[e], 1));                                      \
+                v[e] = __fadd_rn(v[e], __shfl_xor(v[e], 2));                                      \
             }                                                                                     \
             if ((tid & 3) == 0) *reinterpret_cast<f32x4 *>(F2W + rem_pos * PP + 4 * (rem_q ^ swz_sel<R2>(rem_pos))) = v; \
         }                                                                                         \
@@ -468,7 +495,7 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
 
     __syncthreads();
     float *ost = smem;
-    const float cf = (float)p.C;
+    const float cf = (float)p.C, cinv = pow2_reciprocal(p.C);
     if constexpr (R2) {
 #pragma unroll
         for (int i = 0; i < 14; ++i) acc[i] += __shfl_xor(acc[i], 32);      // the two 16-channel halves
@@ -476,7 +503,7 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
             const int fp0 = 16 * (lane >> 3) + (lane & 7);
 #pragma unroll
             for (int t = 0; t < 7; ++t) {
-                float v0 = acc[t] / cf, v1 = acc[7 + t] / cf;
+                float v0 = mean_over_c(acc[t], cf, cinv), v1 = mean_over_c(acc[7 + t], cf, cinv);
                 if (p.leaky) { v0 = lrelu01(v0); v1 = lrelu01(v1); }
                 ost[fp0 * OUTC + 7 * t + grp] = v0;
                 ost[(fp0 + 8) * OUTC + 7 * t + grp] = v1;
@@ -491,7 +518,7 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
         for (int k = 0; k < 7; ++k) {
             const int d = grp + 8 * k;
             if (d < 49) {
-                float v = acc[k] / cf;
+                float v = mean_over_c(acc[k], cf, cinv);
                 if (p.leaky) v = lrelu01(v);
                 ost[lane * OUTC + d] = v;
             }
@@ -645,17 +672,18 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int pos = pq + 64 * u;
-            f32x4 v = tapw[pos] * x[u][0];
-#pragma unroll
-            for (int k = 1; k < NT; ++k) v += tapw[k * NPOS + pos] * x[u][k];
+            f32x4 v;
+            if (NT == 4) v = blend_taps(tapw[pos], tapw[NPOS + pos], tapw[2 * NPOS + pos], tapw[3 * NPOS + pos], x[u][0], x[u][NT > 1 ? 1 : 0], x[u][NT > 2 ? 2 : 0], x[u][NT > 3 ? 3 : 0]);
+            else v = tapw[pos] * x[u][0];
             *reinterpret_cast<f32x4 *>(f2w + pos * PP + 4 * (q16 ^ swz16(pos))) = v;
         }
         if (grp < 4) {                    // waves 0..3: the 64 left-over items, one tap per lane, summed over each lane quad
-            f32x4 v = rem_w * xr;
+            f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] += __shfl_xor(v[e], 1);
-                v[e] += __shfl_xor(v[e], 2);
+                v[e] = __fmul_rn(rem_w, xr[e]);
+                v[e] = __fadd_rn(v[e], __shfl_xor(v[e], 1));
+                v[e] = __fadd_rn(v[e], __shfl_xor(v[e], 2));
             }
             if ((tid & 3) == 0) *reinterpret_cast<f32x4 *>(f2w + rem_pos * PP + 4 * (rem_q ^ swz16(rem_pos))) = v;
         }
@@ -702,12 +730,12 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     __syncthreads();
     WC_STAMP();                                   // 7: barrier 3 passed
     float *ost = smem;                           // [64][56], exact zeros in lanes 49..55
-    const float cf = (float)p.C;
+    const float cf = (float)p.C, cinv = pow2_reciprocal(p.C);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int d = grp + 16 * k;
         if (k < 3 || grp == 0) {
-            float v = (accA[k] + accB[k]) / cf;
+            float v = mean_over_c(accA[k] + accB[k], cf, cinv);
             if (p.leaky) v = lrelu01(v);
             ost[lane * OUTC + d] = v;
         }

@@ -217,7 +217,8 @@ class ParticleSequence:
     wrapped around a margin so the seeding density stays constant.  Frame k is a pure function of (seed, k): every rank can
     render exactly the frames of its shard (plus the halo frame) and all ranks agree on them.
 
-    frames(k0, k1) -> uint8 [k1-k0, H, W].  Rendering is a scatter-add of each particle's 9x9 Gaussian footprint."""
+    frames(k0, k1) -> uint8 [k1-k0, H, W].  Rendering is a scatter-add of each particle's 9x9 Gaussian footprint, in fixed
+    point so that it is bit-reproducible on any device."""
 
     def __init__(self, H: int, W: int, seed: int = 1234, density: float = 0.05, peak: float = 4.0,
                  shift: Tuple[float, float] = (1.5, -0.75), device="cpu"):
@@ -258,7 +259,10 @@ class ParticleSequence:
             ix, iy = torch.floor(x).long() + ox, torch.floor(y).long() + oy
             val = inten[:, None] * torch.exp(-((ix - x) ** 2 + (iy - y) ** 2) / ((0.5 * self.d[:, None]) ** 2))
             ok = (ix >= 0) & (ix < self.W) & (iy >= 0) & (iy < self.H)
-            img = torch.zeros(self.H * self.W, dtype=torch.float32, device=self.device)
-            img.index_add_(0, (iy * self.W + ix)[ok], val[ok])
-            out[k - k0] = img.view(self.H, self.W).clamp_(0, 255).to(torch.uint8)
+            # accumulate in 2^-16 fixed point: integer adds commute, so the frame does not depend on the order in which the
+            # device's atomic adds land (float index_add_ on a GPU does, and a frame could differ by one grey level between
+            # two renderings -- ranks must agree on the halo frame they both render)
+            img = torch.zeros(self.H * self.W, dtype=torch.int64, device=self.device)
+            img.index_add_(0, (iy * self.W + ix)[ok], torch.round(val[ok] * 65536.0).to(torch.int64))
+            out[k - k0] = (img.view(self.H, self.W).to(torch.float64) / 65536.0).clamp_(0, 255).to(torch.uint8)
         return out

@@ -228,7 +228,7 @@ if __name__ == "__main__":
     ap.add_argument("--tune7", type=int, default=0, help="ablation mask of the fp32 conv kernel in a -DPIVLFN_STAMPS build (pivlfn_tune(7, mask))")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
-    ap.add_argument("--variants", default="1,4,0")
+    ap.add_argument("--variants", default="6,8,5")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
     a = ap.parse_args()
     {"conv_stamps": bench_conv_stamps, "warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv}[a.what](a)

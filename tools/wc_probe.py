@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--combos", default="0:0,0:16", help="variant:dbgmask list for the standalone runs (dbg 16 = no L2 prefetch)")
     ap.add_argument("--brief", action="store_true")
+    ap.add_argument("--net-masks", default="0", help="pivlfn_tune(1, .) masks to run the in-network measurement under (2048 = single stream)")
     a = ap.parse_args()
     lib = _toolslib.load()
     _lib._lib = lib                    # the Python surface below talks to the tools build
@@ -88,8 +89,9 @@ def main():
             net(i1, i2)
         torch.cuda.synchronize()
         net.profile_enable(L)
-        for dbg in (0, 16, 0, 16):
-            lib.pivlfn_tune(2, dbg)
+        for mask in [int(m) for m in a.net_masks.split(",")] * 2:
+            dbg = 0
+            lib.pivlfn_tune(1, mask)
             for _ in range(2):
                 net(i1, i2)
             torch.cuda.synchronize()
@@ -104,9 +106,9 @@ def main():
                 _toolslib.set_stamp_buffer(lib, 0, "wc")
                 ms, ems, k = net.profile_read()
                 tot.append(round(ms / max(1, k) * 1e3, 2))
-                report(f"[net dbg {dbg} rep {rep}]", stamps.cpu().numpy(), nwg, brief=rep > 0 or a.brief)
-            print(f"[net dbg {dbg}] dispatch-event time of the level-{L} launch per rep: {tot} us")
-        lib.pivlfn_tune(2, 0)
+                report(f"[net mask {mask} rep {rep}]", stamps.cpu().numpy(), nwg, brief=rep > 0 or a.brief)
+            print(f"[net mask {mask}] dispatch-event time of the level-{L} launch per rep: {tot} us")
+        lib.pivlfn_tune(1, 0)
         net.profile_enable(0)
 
     g = torch.Generator(device=dev).manual_seed(5)
