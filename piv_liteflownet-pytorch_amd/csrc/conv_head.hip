@@ -77,6 +77,90 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float *__restrict_
     }
 }
 
+// ---- large images (levels 1 and 2): four output rows per lane ---------------------------------------------------------
+// The kernel above reads one 16-byte quad of the patch per 8 fused multiply-adds and is bound by LDS read bandwidth and the
+// latency of those reads at two workgroups per CU (a 7x7 head at level 1: 232 us, 20 % of the VALU rate).  Here a lane owns a
+// column of FOUR vertically adjacent output pixels: a quad read at patch row r serves the taps ky = r - i of all four rows i, so
+// ten reads feed 28 (row, tap) products -- 2.8x less LDS traffic per pixel -- and a weight taken from a scalar register is used by
+// four pixels.  Lanes are consecutive pixels in x (conflict-free 16-byte reads with the quad pair of a pixel swapped for
+// columns 8..15 of every 16); a wave covers 16 x 16 pixels, a workgroup 32 x 32; the 32 input channels are staged in four
+// passes of 8 (a 38 x 38 x 32-byte patch, 46 KB: three workgroups per CU).
+template <int K>
+__global__ __launch_bounds__(256, 3) void conv_head4_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            float b0, float b1, const float *__restrict__ res4,
+                                                            float *__restrict__ out4, int B, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int P = K / 2, PW = 32 + K - 1, NPIX = PW * PW, NR = 4 + K - 1;
+    const int tiles_x = (W + 31) >> 5, tiles_y = (H + 31) >> 5;
+    int bid = xcd_remap(blockIdx.x, tiles_x * tiles_y * B);
+    const int tx0 = (bid % tiles_x) * 32;
+    bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * 32;
+    const int b = bid / tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *xb = x + (size_t)b * H * W * 32;
+    const int lx = (wave & 1) * 16 + (lane & 15);          // column of this lane inside the tile
+    const int ly0 = (wave >> 1) * 16 + (lane >> 4) * 4;    // first of its four rows
+
+    float a[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i][0] = a[i][1] = 0.f;
+
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        if (pass) __syncthreads();
+        for (int idx = tid; idx < NPIX * 2; idx += 256) {
+            const int pix = idx >> 1, qq = idx & 1;
+            const int r = pix / PW, c = pix - r * PW;
+            const int iy = ty0 + r - P, ix = tx0 + c - P;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4 *>(xb + ((size_t)iy * W + ix) * 32 + pass * 8 + qq * 4);
+            *reinterpret_cast<f32x4 *>(smem + pix * 8 + 4 * (qq ^ ((c >> 3) & 1))) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kx = 0; kx < K; ++kx) {
+            const int c = lx + kx;
+            const int sw = (c >> 3) & 1;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const float *wq = w + (kx * 8 + pass * 2 + qq) * 8;          // + ky * K * 64: [tap][quad][out][4]
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + ((ly0 + r) * PW + c) * 8 + 4 * (qq ^ sw));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ky = r - i;
+                        if (ky >= 0 && ky < K) {
+                            const float *wk = wq + ky * K * 64;
+                            a[i][0] = fmaf(v[0], wk[0], a[i][0]); a[i][0] = fmaf(v[1], wk[1], a[i][0]);
+                            a[i][0] = fmaf(v[2], wk[2], a[i][0]); a[i][0] = fmaf(v[3], wk[3], a[i][0]);
+                            a[i][1] = fmaf(v[0], wk[4], a[i][1]); a[i][1] = fmaf(v[1], wk[5], a[i][1]);
+                            a[i][1] = fmaf(v[2], wk[6], a[i][1]); a[i][1] = fmaf(v[3], wk[7], a[i][1]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int ox = tx0 + lx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oy = ty0 + ly0 + i;
+        if (oy < H && ox < W) {
+            const size_t pix = ((size_t)b * H + oy) * W + ox;
+            f32x4 o = {a[i][0] + b0, a[i][1] + b1, 0.f, 0.f};
+            if (res4) {
+                const float2 r = *reinterpret_cast<const float2 *>(res4 + pix * 4);
+                o[0] += r.x;
+                o[1] += r.y;
+            }
+            *reinterpret_cast<f32x4 *>(out4 + pix * 4) = o;
+        }
+    }
+}
+
 template <int K>
 static int launch_head_t(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                          hipStream_t st)
@@ -89,8 +173,15 @@ static int launch_head_t(const float *x, const float *w, float b0, float b1, con
         if (int rc = ensure_dyn_lds(attr_b, reinterpret_cast<const void *>(conv_head_kernel<K, true>), (int)lds)) return rc;
     }
     const int nblk = cdiv(W, 16) * cdiv(H, 16) * B;
-    // (per image, so that a pair's flow never depends on its batch mates -- the two variants differ in nothing but the weight path,
-    //  and produce the same bits, but the rule costs nothing)
+    // Kernel choice per IMAGE size, never per batch: a pair's flow must not depend on its batch mates (the four-row kernel sums
+    // in a different order than the two one-pixel variants, which produce the same bits as each other).
+    if ((long)H * W >= 512 * 512 && !(PIV_KNOB(1) & 8192)) {
+        constexpr int PW4 = 32 + K - 1;
+        hipLaunchKernelGGL((conv_head4_kernel<K>), dim3(cdiv(W, 32) * cdiv(H, 32) * B), dim3(256), (size_t)PW4 * PW4 * 8 * sizeof(float), st,
+                           x, w, b0, b1, res4, out4, B, H, W);
+        PIV_CHECK_HIP(hipGetLastError());
+        return PIVLFN_OK;
+    }
     if (cdiv(W, 16) * cdiv(H, 16) <= 512 && !(PIV_KNOB(1) & 1024))
         hipLaunchKernelGGL((conv_head_kernel<K, true>), dim3(nblk), dim3(256), lds, st, x, w, b0, b1, res4, out4, B, H, W);
     else

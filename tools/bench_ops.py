@@ -220,9 +220,45 @@ def bench_conv_stamps(args):
         lib.pivlfn_conv_destroy(h)
 
 
+def bench_head(args):
+    """The 32 -> 2 k x k flow heads (conv_M.6 / conv_S.6) at the fine levels: knob bit 8192 = one pixel per lane (old), 0 = shipped."""
+    import ctypes
+    lib = _toolslib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for name, n, k in (("L1 head 7x7", 1024, 7), ("L2 head 7x7", 512, 7), ("L3 head 5x5", 256, 5)):
+        n = n * args.size // 1024
+        B = args.batch
+        w = (torch.randn(2, 32, k, k) / (32 * k * k) ** 0.5).contiguous()
+        b = torch.randn(2).contiguous()
+        h = ctypes.c_void_p()
+        _chk(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), 2, 32, k, k, ctypes.byref(h)), "create")
+        x = torch.randn(B, n, n, 32, device=dev)
+        res = torch.randn(B, n, n, 4, device=dev)
+        outs = {}
+        for v in (8192, 0):
+            y = torch.empty(B, n, n, 4, device=dev)
+            outs[v] = y
+
+            def fn(v=v, y=y):
+                lib.pivlfn_tune(1, v)
+                _chk(lib.pivlfn_conv_head_nhwc(h, x.data_ptr(), res.data_ptr(), y.data_ptr(), B, n, n, st), "head")
+            tmin, tmed = time_it(fn, n=20, rounds=4)
+            flop = 2.0 * B * n * n * 2 * 32 * k * k
+            print(f"{name} B={B} {n}x{n} knob {v}: min {tmin:8.1f} us  med {tmed:8.1f} us  {flop / tmin / 1e6:6.1f} TFLOP/s", flush=True)
+        want = torch.nn.functional.conv2d(x[:1].permute(0, 3, 1, 2).double().cpu(), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
+        want = want + res[:1, ..., :2].double().cpu()
+        for v in (8192, 0):
+            err = (outs[v][:1, ..., :2].double().cpu() - want).abs().max().item() / want.abs().max().item()
+            pad = outs[v][..., 2:].abs().max().item()
+            print(f"    knob {v}: max rel err vs float64 conv {err:.2e}, padding lanes max {pad:.1e}")
+        lib.pivlfn_conv_destroy(h)
+    lib.pivlfn_tune(1, 0)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv", "conv_stamps"])
+    ap.add_argument("what", choices=["warp_corr", "wc_ablate", "conv", "conv_stamps", "head"])
     ap.add_argument("--filter", default="")
     ap.add_argument("--tune3", type=int, default=0, help="ablation mask of the fp16 conv kernel (pivlfn_tune(3, mask))")
     ap.add_argument("--tune7", type=int, default=0, help="ablation mask of the fp32 conv kernel in a -DPIVLFN_STAMPS build (pivlfn_tune(7, mask))")
@@ -231,4 +267,4 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="6,8,5")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
     a = ap.parse_args()
-    {"conv_stamps": bench_conv_stamps, "warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv}[a.what](a)
+    {"conv_stamps": bench_conv_stamps, "warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv, "head": bench_head}[a.what](a)
