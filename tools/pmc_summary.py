@@ -18,17 +18,32 @@ tiles = (n // s // 8) ** 2
 
 
 def counters(tag):
-    vals = {}
+    """Counter values of the level's launches.  Level 3 at batch 1 is the latency kernel, one workgroup per tile (256).  Levels 1
+    and 2 run on the persistent throughput kernel with 512 workgroups each: inside a forward the level-2 launch comes first, and
+    bench.py's batch-8 measurement at the end uses the same grid -- so the first 2 x (number of forwards) such dispatches are
+    (level 2, level 1) pairs."""
+    rows = []
     for path in glob.glob(os.path.join(out_dir, tag, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(path)):
-            if "warp_corr" not in r["Kernel_Name"]:
-                continue
-            wg = int(r["Workgroup_Size"]) if "Workgroup_Size" in r else int(r["Workgroup_Size_X"])
-            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
-            if grid // wg != tiles:
-                continue
-            vals.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
-            vals[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+        rows += [r for r in csv.DictReader(open(path)) if "warp_corr" in r["Kernel_Name"]]
+    def nwg(r):
+        wg = int(r["Workgroup_Size"]) if "Workgroup_Size" in r else int(r["Workgroup_Size_X"])
+        grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
+        return grid // wg
+    by_disp = {}
+    for r in rows:
+        by_disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
+    ids = sorted(by_disp)
+    nfwd = sum(1 for d in ids if nwg(by_disp[d][0]) == 256 and "v4" in by_disp[d][0]["Kernel_Name"])
+    if level == 3:
+        pick = [d for d in ids if nwg(by_disp[d][0]) == 256 and "v4" in by_disp[d][0]["Kernel_Name"]]
+    else:
+        cand = [d for d in ids if nwg(by_disp[d][0]) == 512 and "v3" in by_disp[d][0]["Kernel_Name"]][:2 * nfwd]
+        pick = cand[(1 if level == 1 else 0)::2]
+    vals = {}
+    for d in pick:
+        for r in by_disp[d]:
+            vals.setdefault(r["Counter_Name"], {}).setdefault(d, 0.0)
+            vals[r["Counter_Name"]][d] += float(r["Counter_Value"])
             vals["_kernel"] = r["Kernel_Name"]
     return vals
 
@@ -44,7 +59,7 @@ for rel in ("piv_liteflownet-pytorch_amd/csrc/warp_corr.hip", "piv_liteflownet-p
 no = n // s
 alg = 4 * (C * no * no + C * n * n + 2 * n * n + 49 * no * no)
 print(json.dumps({
-    "kernel": f"{res.get('_kernel', '?')} (level {level} of PIV 1024x1024 B=1: C={C}, stride {s}, {tiles} workgroups)",
+    "kernel": f"{res.get('_kernel', '?')} (level {level} of PIV 1024x1024 B=1: C={C}, stride {s}, {tiles} tiles)",
     "launches_averaged": len(res.get("FETCH_SIZE", {})),
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane reads; MI355X_MICROARCH.md section HBM); WRITE_SIZE exact",
