@@ -131,7 +131,7 @@ def l3_throughput_regime(dev, batch=8, launches=40):
 
     def launch():
         _lib.check(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out.data_ptr(), batch, C, n, n, s, 1, st), "wc")
-    for _ in range(5):
+    for _ in range(20):          # clocks and caches in their steady state for this launch pattern
         launch()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

@@ -296,11 +296,7 @@ __device__ __forceinline__ int swz_sel(int pos)
 }
 __device__ __forceinline__ int swz_f1_r2(int fpp) { return ((fpp >> 1) & 3) | (((fpp >> 5) & 1) << 2); }
 
-// PERSIST: a workgroup walks the tiles slot, slot + S, ... of its XCD's band (S = workgroups per XCD) and reads the NEXT tile's flow
-// while the current tile is being gathered, so that the one dependent round trip in front of every tile's gathers (flow -> taps ->
-// addresses) disappears from all tiles but the first.  (The round-1 attempt at this spilled: the kernel sat at 127 registers; the
-// cheaper LDS addressing below freed 13.)
-template <bool HASFLOW, bool R2, bool PERSIST>
+template <bool HASFLOW, bool R2>
 __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -313,61 +309,27 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
 
     const int tiles_x = (p.Wo + TO - 1) / TO, tiles_y = (p.Ho + TO - 1) / TO;
     const int nblk = tiles_x * tiles_y * p.B;
-    if (p.dbg & 8) return;
-    const int tid0 = threadIdx.x;
-    const int grp = __builtin_amdgcn_readfirstlane(tid0 >> 6);     // wave id, provably uniform
-    const size_t img = (size_t)p.H * p.W;
-    const unsigned img_bytes = (unsigned)(img * p.C * sizeof(float));
-    const unsigned pix_bytes = (unsigned)p.C * 4u;
-    // tiles of this workgroup: its XCD's contiguous band (same split as xcd_remap), one tile or every S-th one
-    const int bq_ = nblk >> 3, br_ = nblk & 7, xcd_ = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
-    const int band0 = (xcd_ < br_) ? xcd_ * (bq_ + 1) : br_ * (bq_ + 1) + (xcd_ - br_) * bq_;
-    const int bandn = bq_ + (xcd_ < br_ ? 1 : 0);
-    const int nslot = PERSIST ? (int)(gridDim.x >> 3) : bandn;
-
-    // Flow of tile `tl` of the band -> LDS, one 16-byte (u, v, 0, 0) element per tile position, by LDS-DMA (global_load_lds_dwordx4:
-    // no registers held while it is in flight; the element of lane l lands at base + 16 l).  A wave reads back only what its own
-    // lanes fetched, after a vmcnt wait that covers the DMA.
-    float *flds = reinterpret_cast<float *>(tapw + 4 * NPOS);          // [NPOS][4]
-    auto fetch_flow = [&](int tl, int tid) {
-        if (!HASFLOW) return;
-        const int a_r = tid / TP - 3, a_c = tid % TP - 3;          // this thread's tile position (threads < NPOS)
-        int bid = band0 + tl;
-        const int tx = bid % tiles_x;
-        bid /= tiles_x;
-        const int ty = bid % tiles_y, b = bid / tiles_y;
-        const int iy = (ty * TO + a_r) * p.s, ix = (tx * TO + a_c) * p.s;
-        if (tid < NPOS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {       // positions outside the image never use their flow
-            const float *src = p.flow + ((size_t)b * img + (size_t)iy * p.W + ix) * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(flds + (tid & ~63) * 4), 16, 0, 0);
-        }
-    };
-    if (slot_ < bandn) fetch_flow(slot_, tid0);
-
-    for (int tl = slot_; tl < bandn; tl += nslot) {
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));          // opaque per tile: nothing derived from the thread id is kept live across tiles
-    const int lane = tid & 63;
-    const int a_r = tid / TP - 3, a_c = tid % TP - 3;              // this thread's tile position (threads < NPOS)
-    int bid = band0 + tl;
+    int bid = xcd_remap(blockIdx.x, nblk);
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int ox0 = tx * TO, oy0 = ty * TO;
+    if (p.dbg & 8) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform
+    const size_t img = (size_t)p.H * p.W;
+    const unsigned img_bytes = (unsigned)(img * p.C * sizeof(float));
+    const unsigned pix_bytes = (unsigned)p.C * 4u;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
 
     WC_STAMP_DECL;
     WC_STAMP();
-    const int a_iy = (oy0 + a_r) * p.s, a_ix = (ox0 + a_c) * p.s;
+    const int a_iy = (oy0 + tid / TP - 3) * p.s, a_ix = (ox0 + tid % TP - 3) * p.s;
     const bool a_in = tid < NPOS && a_iy >= 0 && a_iy < p.H && a_ix >= 0 && a_ix < p.W;
     float2 uv = {0.f, 0.f};
-    if (HASFLOW) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's flow has landed (fetched during the previous tile)
-        if (tid < NPOS) uv = *reinterpret_cast<const float2 *>(flds + tid * 4);
-    }
+    if (HASFLOW && a_in) uv = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * img + (size_t)a_iy * p.W + a_ix) * 4);
     if (tid < NPOS) {
         const int iy = a_iy, ix = a_ix;
         unsigned o0 = OOB, o1 = OOB, o2 = OOB, o3 = OOB;
@@ -526,7 +488,6 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
     } while (0)
 
     WC3_ISSUE(xa, fa, ra, 0);
-    if (PERSIST && tl + nslot < bandn) fetch_flow(tl + nslot, tid);        // in flight under this whole tile
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
         float *buf = smem + (c & 1) * BUF;
@@ -588,24 +549,21 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
     }
     WC_STAMP();
     WC_STAMP_FLUSH();
-    }   // tile loop
 }
 
-template <bool HASFLOW, bool R2, bool PERSIST>
+template <bool HASFLOW, bool R2>
 static int launch_wc3(const WcParams &p, hipStream_t st)
 {
-    const size_t lds = ((size_t)2 * (NPOS + 64) * 32 + 8 * NPOS + 4 * 256) * sizeof(float);      // two chunk buffers, tap table, flow
+    const size_t lds = ((size_t)2 * (NPOS + 64) * 32 + 8 * NPOS) * sizeof(float);
     PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
     static LdsAttr attr;
-    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_v3_kernel<HASFLOW, R2, PERSIST>), (int)lds)) return rc;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_v3_kernel<HASFLOW, R2>), (int)lds)) return rc;
     const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
-    // persistent: two workgroups per CU (73 KB of LDS each), 64 per XCD; one tile per workgroup otherwise
-    const int grid = PERSIST ? 8 * std::min(64, cdiv(nblk, 8)) : nblk;
     if (g_ev_start) {
-        hipExtLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW, R2, PERSIST>), dim3(grid), dim3(512), lds, st, g_ev_start, g_ev_stop, 0, p);
+        hipExtLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW, R2>), dim3(nblk), dim3(512), lds, st, g_ev_start, g_ev_stop, 0, p);
         g_ev_start = g_ev_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW, R2, PERSIST>), dim3(grid), dim3(512), lds, st, p);
+        hipLaunchKernelGGL((warp_corr_v3_kernel<HASFLOW, R2>), dim3(nblk), dim3(512), lds, st, p);
     }
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
@@ -863,10 +821,8 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
         const long tiles = (long)cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * B;
         if ((variant == 0 && C % 64 == 0 && tiles <= 512) || (variant == 5 && C % 64 == 0))
             return flow ? launch_wc4<true>(p, st) : launch_wc4<false>(p, st);
-        if (variant == 4) return flow ? launch_wc3<true, false, false>(p, st) : launch_wc3<false, false, false>(p, st);     // A/B: one pixel per lane
-        if (variant == 6) return flow ? launch_wc3<true, true, false>(p, st) : launch_wc3<false, true, false>(p, st);         // A/B: one tile per workgroup
-        if (variant == 0 || variant == 5 || variant == 9)
-            return flow ? launch_wc3<true, true, true>(p, st) : launch_wc3<false, true, false>(p, st);
+        if (variant == 4) return flow ? launch_wc3<true, false>(p, st) : launch_wc3<false, false>(p, st);     // A/B: one pixel per lane
+        if (variant == 0 || variant == 5 || variant == 6) return flow ? launch_wc3<true, true>(p, st) : launch_wc3<false, true>(p, st);
         PIV_REQUIRE(false, "warp_corr: unknown kernel variant %d", variant);
     }
     if (C % 64 == 0) return launch_wc<64, false>(p, st);

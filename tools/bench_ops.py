@@ -56,6 +56,7 @@ def bench_warp_corr(args):
         flow_ptr = fl.data_ptr() if L < 6 else None
         outs = {}
         alg = 4 * B * (C * no * no + C * n * n + (2 * n * n if L < 6 else 0) + 49 * no * no)
+        fns = {}
         for v in variants:
             out = torch.empty(B, no, no, 56, device=dev)
             outs[v] = out
@@ -63,7 +64,25 @@ def bench_warp_corr(args):
             def fn(v=v, out=out):
                 lib.pivlfn_tune(0, v)
                 _chk(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), flow_ptr, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
-            tmin, tmed = time_it(fn)
+            fns[v] = fn
+        # interleaved rounds (clock state and neighbours are shared by all variants): min / median over the rounds
+        times = {v: [] for v in variants}
+        for _ in range(3):
+            for v in variants:
+                fns[v]()
+        for rnd in range(args.rounds):
+            for v in (variants if rnd % 2 == 0 else variants[::-1]):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                fns[v]()
+                torch.cuda.synchronize()
+                a.record()
+                for _ in range(50):
+                    fns[v]()
+                b.record()
+                torch.cuda.synchronize()
+                times[v].append(a.elapsed_time(b) / 50 * 1e3)
+        for v in variants:
+            tmin, tmed = min(times[v]), sorted(times[v])[len(times[v]) // 2]
             print(f"L{L} B={B} C={C} {n}x{n} s={s} variant {v}: min {tmin:8.2f} us  med {tmed:8.2f} us   "
                   f"{alg / tmin / 1e3:8.1f} GB/s algorithmic ({alg / 1e6:.2f} MB)", flush=True)
         ref = outs[variants[0]]
@@ -266,5 +285,6 @@ if __name__ == "__main__":
     ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
     ap.add_argument("--variants", default="6,8,5")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
+    ap.add_argument("--rounds", type=int, default=8, help="interleaved timing rounds per variant (warp_corr)")
     a = ap.parse_args()
     {"conv_stamps": bench_conv_stamps, "warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv, "head": bench_head}[a.what](a)
