@@ -644,14 +644,17 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
     if ((pm > 3 || wm > 9) && mt == 2 && nt >= 3) { mt = 1; need(mt, nt, pm, wm); }   // keep the big-staging class under 256 VGPRs
     if (pm > 9 || wm > 13) return -1;      // not covered: caller falls back to v1
     const bool small = pm <= 3 && wm <= 9;
+    // a middle staging class (<= 5 patch loads, <= 5 slab loads per thread) for the k x 1 layers of conv_dist_R (7 x 1: a 14-row
+    // patch, 4 + 4 loads): 168 instead of 240 registers, three workgroups per CU instead of two
+    const bool mid = !small && pm <= 5 && wm <= 5 && !(PIV_KNOB(1) & 4);
 #define PICK(MT_, NT_)                                                                     \
     (small ? launch_t2<MT_, NT_, 3, 9>(p, st) : launch_t2<MT_, NT_, 9, 13>(p, st))
     if (mt == 2) {
         switch (nt) {
             case 4: return small ? launch_t2<2, 4, 3, 9>(p, st) : -1;
             case 3: return small ? launch_t2<2, 3, 3, 9>(p, st) : -1;
-            case 2: return PICK(2, 2);
-            default: return PICK(2, 1);
+            case 2: return mid ? launch_t2<2, 2, 5, 5>(p, st) : PICK(2, 2);
+            default: return mid ? launch_t2<2, 1, 5, 5>(p, st) : PICK(2, 1);
         }
     }
     switch (nt) {

@@ -119,13 +119,14 @@ class LiteFlowNet(torch.nn.Module):
     def _key(self):
         # the parameter list is cached: walking the 250-module tree on every forward costs 2 ms of host time, which is what
         # a small or fp16-mode forward takes on the GPU (load_state_dict / .to() change data in place or swap .data: both
-        # show up in _version / data_ptr, and _apply() drops the cache)
+        # show up in _version / data_ptr, and _apply() drops the cache); the key itself costs ~50 us for 252 parameters
         ps = self.__dict__.get("_plist")
         if ps is None or self.__dict__.get("_plist_gen") != _PARAM_GEN[0]:
             ps = list(self.parameters())
             self.__dict__["_plist"] = ps
             self.__dict__["_plist_gen"] = _PARAM_GEN[0]
-        return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]))
+        # every parameter's storage address is part of the key: `p.data = new_tensor` (weight surgery, EMA swaps) bumps no version
+        return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__["_plist"] = None

@@ -275,3 +275,15 @@ def test_replacing_a_parameter_object_takes_effect(dev):
     mod.weight = torch.nn.Parameter(mod.weight.detach() * 0.5, requires_grad=False)
     after = net(i1, i2)
     assert not torch.equal(before, after)
+
+
+def test_swapping_parameter_data_takes_effect(dev):
+    """`p.data = new_tensor` on a LATE parameter (no _version bump, a new storage address): the native weights must be rebuilt."""
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    a, b = synth.particle_batch(1, 64, 64, seed=9)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    before = net(i1, i2).clone()
+    late = list(net.parameters())[-8]
+    late.data = (late.data * 0.25).clone()
+    after = net(i1, i2)
+    assert not torch.equal(before, after)
