@@ -122,40 +122,38 @@ int launch_resize_nchw(const float *in, float *out, int B, int C, int H, int W, 
 // ---- upConv_M / upCorr_M (:144-145, 151-152): depthwise ConvTranspose2d k4 s2 p1, no bias ----------------------
 // out[oy,ox,c] = sum over the (at most 2x2) input pixels with oy = 2*iy - 1 + ky, ox = 2*ix - 1 + kx.
 // w: [16 taps][C4] (zero lanes for padding channels, so padding lanes stay exact zeros); 32-bit index math.
+// One workgroup row segment: blockIdx = (segment of 256 (pixel, quad) items along an output row, output row, image), Q a compile-time
+// constant -- no run-time division anywhere (the flat-index form spent more on i % Q, / Wo, % Ho than on its four loads).
+template <int Q>
 __global__ __launch_bounds__(256) void dwconvT_kernel(const float *__restrict__ in, const float *__restrict__ w,
-                                                      float *__restrict__ out, int B, int H, int W, int Q, int sin, int sout)
+                                                      float *__restrict__ out, int H, int W, int sin, int sout)
 {
-    const unsigned Ho = 2 * H, Wo = 2 * W;
-    const unsigned total = (unsigned)B * Ho * Wo * Q;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const unsigned q = i % Q;
-        unsigned r = i / Q;
-        const unsigned ox = r % Wo;
-        r /= Wo;
-        const unsigned oy = r % Ho;
-        const unsigned b = r / Ho;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int ox = j / Q, q = j - ox * Q;
+    if (ox >= Wo) return;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int ky = ky0 + 2 * a;
-            const int iy = ((int)oy + 1 - ky) >> 1;
-            if (iy < 0 || iy >= H) continue;
+    for (int a = 0; a < 2; ++a) {
+        const int ky = ky0 + 2 * a;
+        const int iy = (oy + 1 - ky) >> 1;
+        if (iy < 0 || iy >= H) continue;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int kx = kx0 + 2 * c;
-                const int ix = ((int)ox + 1 - kx) >> 1;
-                if (ix < 0 || ix >= W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + iy) * W + ix) * sin + 4 * q);
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + ((ky * 4 + kx) * Q + q) * 4);
-                acc[0] = fmaf(v[0], wv[0], acc[0]);
-                acc[1] = fmaf(v[1], wv[1], acc[1]);
-                acc[2] = fmaf(v[2], wv[2], acc[2]);
-                acc[3] = fmaf(v[3], wv[3], acc[3]);
-            }
+        for (int c = 0; c < 2; ++c) {
+            const int kx = kx0 + 2 * c;
+            const int ix = (ox + 1 - kx) >> 1;
+            if (ix < 0 || ix >= W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + iy) * W + ix) * sin + 4 * q);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + ((ky * 4 + kx) * Q + q) * 4);
+            acc[0] = fmaf(v[0], wv[0], acc[0]);
+            acc[1] = fmaf(v[1], wv[1], acc[1]);
+            acc[2] = fmaf(v[2], wv[2], acc[2]);
+            acc[3] = fmaf(v[3], wv[3], acc[3]);
         }
-        *reinterpret_cast<f32x4 *>(out + ((size_t)(b * Ho + oy) * Wo + ox) * sout + 4 * q) = acc;
     }
+    *reinterpret_cast<f32x4 *>(out + ((size_t)(b * Ho + oy) * Wo + ox) * sout + 4 * q) = acc;
 }
 
 int launch_dwconvT(const float *in, const float *w, float *out, int B, int H, int W, int C, int stride_in,
@@ -163,9 +161,13 @@ int launch_dwconvT(const float *in, const float *w, float *out, int B, int H, in
 {
     (void)C;
     const int Q = cstore / 4;
-    const size_t total = (size_t)B * 4 * H * W * Q;
-    PIV_REQUIRE(total < 0x7fffffffull, "dwconvT: %zu work items exceed the 32-bit index range", total);
-    hipLaunchKernelGGL(dwconvT_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, w, out, B, H, W, Q, stride_in, stride_out);
+    PIV_REQUIRE(2 * H <= 65535 && B <= 65535, "dwconvT: %d output rows / %d images exceed the grid range", 2 * H, B);
+    const dim3 grid((unsigned)cdiv(2 * W * Q, 256), (unsigned)(2 * H), (unsigned)B);
+    switch (Q) {
+        case 1: hipLaunchKernelGGL(dwconvT_kernel<1>, grid, dim3(256), 0, st, in, w, out, H, W, stride_in, stride_out); break;       // flow (u, v, 0, 0)
+        case 14: hipLaunchKernelGGL(dwconvT_kernel<14>, grid, dim3(256), 0, st, in, w, out, H, W, stride_in, stride_out); break;     // 49 + 7 correlation lanes
+        default: PIV_REQUIRE(false, "dwconvT: %d channel quads not instantiated (1 = flow, 14 = correlation)", Q);
+    }
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
@@ -305,6 +307,9 @@ int launch_reg_prep(const float *img1, const float *img2, const float *flow4, co
 
 // ---- Regularization tail (:281-302): softmax(-d^2) weighted k x k local average of u and v -----------------------
 // e_c = exp(-d_c^2 - max_c(-d_c^2)); Z = 1/sum e; u' = (bx + sum_c wx[c] e_c u[y+ky-p, x+kx-p]) * Z  (bias inside, :288-300)
+// One workgroup = a 16 x 16 tile of pixels, one pixel per thread.  The k x k neighbourhood of (u, v) every pixel needs (the
+// F.unfold of :290-299) comes from an LDS copy of the tile's (16 + k - 1)^2 flow halo: read from global memory, the 49 neighbour
+// loads per pixel were what the 7 x 7 tail at level 1 spent its time on (95 us; the dist rows themselves are 235 MB = 45 us).
 template <int K>
 __global__ __launch_bounds__(256) void reg_tail_kernel(const float *__restrict__ dist, int dstride,
                                                        const float *__restrict__ flow4, const float *__restrict__ wx,
@@ -312,54 +317,63 @@ __global__ __launch_bounds__(256) void reg_tail_kernel(const float *__restrict__
                                                        float *__restrict__ out4, float *__restrict__ out_nchw,
                                                        float out_scale, int B, int H, int W)
 {
-    constexpr int KK = K * K, P = K / 2;
+    constexpr int KK = K * K, P = K / 2, TW = 16 + K - 1;
+    __shared__ float2 fl[TW * TW];
     const size_t img = (size_t)H * W;
-    const unsigned total = (unsigned)B * H * W;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const int x = (int)(i % (unsigned)W);
-        const unsigned r = i / (unsigned)W;
-        const int y = (int)(r % (unsigned)H);
-        const int b = (int)(r / (unsigned)H);
-        float e[KK];
-        const float *dp = dist + (size_t)i * dstride;
-        float m = -INFINITY;
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * 16;
+    bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * 16;
+    const int b = bid / tiles_y;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TW * TW; i += 256) {
+        const int yy = ty0 + i / TW - P, xx = tx0 + i % TW - P;
+        float2 uv = make_float2(0.f, 0.f);                    // zero padding of F.unfold
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            uv = *reinterpret_cast<const float2 *>(flow4 + ((size_t)b * img + (size_t)yy * W + xx) * 4);
+        fl[i] = uv;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)b * img + (size_t)y * W + x;
+    float e[KK];
+    const float *dp = dist + i * dstride;
+    float m = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < KK; ++c) {
-            const float d = dp[c];
-            e[c] = -(d * d);
-            m = fmaxf(m, e[c]);
-        }
-        float z = 0.f, su = 0.f, sv = 0.f;
+    for (int c = 0; c < KK; ++c) {
+        const float d = dp[c];
+        e[c] = -(d * d);
+        m = fmaxf(m, e[c]);
+    }
+    float z = 0.f, su = 0.f, sv = 0.f;
 #pragma unroll
-        for (int c = 0; c < KK; ++c) {
-            e[c] = expf(e[c] - m);
-            z += e[c];
-            const int yy = y + c / K - P, xx = x + c % K - P;
-            float2 uv = make_float2(0.f, 0.f);
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                uv = *reinterpret_cast<const float2 *>(flow4 + ((size_t)b * img + (size_t)yy * W + xx) * 4);
-            su = fmaf(wx[c], e[c] * uv.x, su);
-            sv = fmaf(wy[c], e[c] * uv.y, sv);
-        }
-        const float zi = 1.f / z;
-        const float u = (su + bx) * zi, v = (sv + by) * zi;
-        if (out4) {
-            f32x4 o = {u, v, 0.f, 0.f};
-            reinterpret_cast<f32x4 *>(out4)[i] = o;
-        }
-        if (out_nchw) {
-            const size_t pix = (size_t)y * W + x;
-            out_nchw[((size_t)b * 2 + 0) * img + pix] = u * out_scale;
-            out_nchw[((size_t)b * 2 + 1) * img + pix] = v * out_scale;
-        }
+    for (int c = 0; c < KK; ++c) {
+        e[c] = expf(e[c] - m);
+        z += e[c];
+        const float2 uv = fl[(ly + c / K) * TW + lx + c % K];
+        su = fmaf(wx[c], e[c] * uv.x, su);
+        sv = fmaf(wy[c], e[c] * uv.y, sv);
+    }
+    const float zi = 1.f / z;
+    const float u = (su + bx) * zi, v = (sv + by) * zi;
+    if (out4) {
+        f32x4 o = {u, v, 0.f, 0.f};
+        reinterpret_cast<f32x4 *>(out4)[i] = o;
+    }
+    if (out_nchw) {
+        const size_t pix = (size_t)y * W + x;
+        out_nchw[((size_t)b * 2 + 0) * img + pix] = u * out_scale;
+        out_nchw[((size_t)b * 2 + 1) * img + pix] = v * out_scale;
     }
 }
 
 int launch_reg_tail(const float *dist, int dstride, const float *flow4, const float *wx, const float *wy, float bx,
                     float by, int k, float *out4, float *out_nchw, float out_scale, int B, int H, int W, hipStream_t st)
 {
-    const size_t total = (size_t)B * H * W;
-    const dim3 g(grid_for(total)), t(256);
+    const dim3 g((unsigned)(cdiv(W, 16) * cdiv(H, 16) * B)), t(256);
     switch (k) {
         case 3: hipLaunchKernelGGL(reg_tail_kernel<3>, g, t, 0, st, dist, dstride, flow4, wx, wy, bx, by, out4, out_nchw, out_scale, B, H, W); break;
         case 5: hipLaunchKernelGGL(reg_tail_kernel<5>, g, t, 0, st, dist, dstride, flow4, wx, wy, bx, by, out4, out_nchw, out_scale, B, H, W); break;
