@@ -43,6 +43,7 @@ struct WcParams {
     float scale;
     int B, C, H, W, s, Ho, Wo, leaky;
     int dbg;      // ablation mask for tools/bench_ops.py (0 in production): 1 skip dot products, 2 skip gathers, 4 skip store, 8 exit at entry
+    int strips;   // 1: walk the tiles in strips of 8 tile rows, column by column (wide images; see warp_corr_v3_kernel)
     unsigned long long *stamps;   // tools build only: per-workgroup phase stamps (16 u64 per record, 2 records per workgroup); nullptr in production
 };
 
@@ -310,10 +311,26 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
     const int tiles_x = (p.Wo + TO - 1) / TO, tiles_y = (p.Ho + TO - 1) / TO;
     const int nblk = tiles_x * tiles_y * p.B;
     int bid = xcd_remap(blockIdx.x, nblk);
-    const int tx = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
+    int tx, ty, b;
+    if (p.strips) {
+        // Wide images: one tile row's f2 footprint ((8+6)*s rows x W px x C) no longer fits an XCD's 4 MB L2, so in row-major order
+        // the 6*s halo rows shared with the next tile row are gone by the time it starts.  Walk strips of 8 tile rows column by
+        // column instead: the ~64 workgroups an XCD runs at a time then cover a compact 8x8 block of tiles whose halos overlap
+        // while they are still resident; only the 6*s rows between strips are fetched twice.
+        const int per_img = tiles_x * tiles_y;
+        b = bid / per_img;
+        const int t = bid - b * per_img;
+        const int strip = t / (8 * tiles_x);
+        const int rows = min(8, tiles_y - strip * 8);
+        const int w = t - strip * 8 * tiles_x;
+        tx = w / rows;
+        ty = strip * 8 + (w - tx * rows);
+    } else {
+        tx = bid % tiles_x;
+        bid /= tiles_x;
+        ty = bid % tiles_y;
+        b = bid / tiles_y;
+    }
     const int ox0 = tx * TO, oy0 = ty * TO;
     if (p.dbg & 8) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -807,10 +824,12 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
     PIV_REQUIRE(f1 && f2 && out, "warp_corr: null pointer");
     PIV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "warp_corr: empty shape B=%d C=%d H=%d W=%d", B, C, H, W);
     PIV_REQUIRE(stride >= 1 && stride <= 4, "warp_corr: stride=%d unsupported", stride);
-    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, PIV_KNOB(2),
+    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, PIV_KNOB(2), 0,
                reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(10) << 32) | (unsigned)PIV_KNOB(9))};
     if (nhwc) {
         PIV_REQUIRE(C % 32 == 0, "warp_corr (channels-last): C=%d must be a multiple of 32", C);
+        // f2 rows under one row of tiles: beyond half an XCD's L2 the row-major walk loses the halo rows between tile rows
+        p.strips = (size_t)(TO + 6) * stride * W * C * sizeof(float) > (size_t)(2 << 20) && !(PIV_KNOB(1) & 32768);
         const int variant = wc_variant();
         if (variant == 1) {                       // v1 kernel, kept for A/B measurements (PIVLFN_WC_VARIANT=1)
             if (C % 64 == 0) return launch_wc<64, true>(p, st);

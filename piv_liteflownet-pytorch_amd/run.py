@@ -166,7 +166,7 @@ def main(argv: Optional[List[str]] = None) -> int:
         raise SystemExit("run.py: this build has no CPU path (the reference's correlation has none either, "
                          "src/correlation.py:339-340); a GPU is required")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())   # ranks may share a card
     torch.cuda.set_device(device)
     weights, netname = load_weights(args)
     net = Network(model=args.model, params=weights, version=args.version).to(device).eval()

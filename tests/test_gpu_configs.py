@@ -263,3 +263,44 @@ def test_two_nets_two_threads_two_streams(dev):
     assert not errs, errs
     for t in range(2):
         assert torch.equal(got[t], want[t])
+
+
+# ---- run.py sharded over ranks, Inference.images_parsing -----------------------------------------------------------------
+def test_run_py_two_ranks_write_disjoint_shards(tmp_path, dev):
+    """`torch.distributed.run`-style launch of run.py (RANK / WORLD_SIZE in the environment): every rank estimates and writes
+    its contiguous shard of the folder's pairs; together the files are exactly the single-process result."""
+    import PIL.Image
+    seq = tmp_path / "seq"
+    seq.mkdir()
+    for k in range(6):
+        a, _, _ = synth.particle_pair(64, 64, 700 + k)
+        PIL.Image.fromarray(a).save(str(seq / f"f_{k:03d}.png"))
+    run_py = os.path.join(ROOT, "piv_liteflownet-pytorch_amd", "run.py")
+    one = tmp_path / "one"
+    two = tmp_path / "two"
+    _run_children(lambda r: [sys.executable, run_py, "-m", "piv", "-i", str(seq), "-o", str(one), "--batch", "2"], 1, {})
+    outs = _run_children(lambda r: [sys.executable, run_py, "-m", "piv", "-i", str(seq), "-o", str(two), "--batch", "2"], 2, {})
+    assert "Processing 3 of 5 pairs" in outs[0][1] and "Processing 2 of 5 pairs" in outs[1][1]
+    d1, d2 = one / "piv-synthetic" / "seq" / "flow", two / "piv-synthetic" / "seq" / "flow"
+    names = sorted(os.listdir(d1))
+    assert names == [f"f_{k:03d}_out.flo" for k in range(5)] and sorted(os.listdir(d2)) == names
+    for n in names:
+        assert open(d1 / n, "rb").read() == open(d2 / n, "rb").read()
+
+
+def test_inference_images_parsing(tmp_path, dev):
+    """`Inference(net, ...).images_parsing(dir, pair)` (inference.py:120-171): paired folder -> <out>/<net>/<dir>_parse/*.flo."""
+    import PIL.Image
+    d = tmp_path / "shots"
+    d.mkdir()
+    a, b, _ = synth.particle_pair(64, 96, 811)
+    PIL.Image.fromarray(a).save(str(d / "s0_img1.png"))
+    PIL.Image.fromarray(b).save(str(d / "s0_img2.png"))
+    PIL.Image.fromarray(a).save(str(d / "lonely_img1.png"))          # no partner: skipped
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    inf = pivlfn.Inference(net, netname="weights/PIV-x.paramOnly", output_dir=str(tmp_path / "out"), device=dev)
+    flows = inf.images_parsing(str(d), pair=True)
+    assert len(flows) == 1 and flows[0].shape == (64, 96, 2)
+    got = read_flow(str(tmp_path / "out" / "PIV-x" / "shots_parse" / "s0_out.flo"))
+    want = pivlfn.estimate(net, torch.from_numpy(synth.to_input(a))[None].to(dev), torch.from_numpy(synth.to_input(b))[None].to(dev))
+    assert np.array_equal(got, want) and np.array_equal(flows[0], want)

@@ -13,4 +13,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
 done
 python3 tools/pmc_summary.py "$OUT" 3 > "$OUT/r02_pmc_l3_warp_corr.json"
 python3 tools/pmc_summary.py "$OUT" 1 > "$OUT/r02_pmc_l1_warp_corr.json"
-cat "$OUT/r02_pmc_l3_warp_corr.json" "$OUT/r02_pmc_l1_warp_corr.json"
+python3 tools/pmc_summary.py "$OUT" 3 8 > "$OUT/r02_pmc_l3b8_warp_corr.json"
+cat "$OUT/r02_pmc_l3_warp_corr.json" "$OUT/r02_pmc_l1_warp_corr.json" "$OUT/r02_pmc_l3b8_warp_corr.json"

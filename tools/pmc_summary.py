@@ -13,15 +13,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir, level = sys.argv[1], int(sys.argv[2])
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # 8: bench.py's standalone batch-8 level-3 launches (`roofline_batch8`)
 C, n, s = {1: (64, 1024, 2), 2: (64, 512, 2), 3: (64, 256, 2)}[level]
-tiles = (n // s // 8) ** 2
+tiles = (n // s // 8) ** 2 * batch
 
 
 def counters(tag):
-    """Counter values of the level's launches.  Level 3 at batch 1 is the latency kernel, one workgroup per tile (256).  Levels 1
-    and 2 run on the persistent throughput kernel with 512 workgroups each: inside a forward the level-2 launch comes first, and
-    bench.py's batch-8 measurement at the end uses the same grid -- so the first 2 x (number of forwards) such dispatches are
-    (level 2, level 1) pairs."""
+    """Counter values of the level's launches: both kernels run one tile per workgroup, so the launch of a level is the one whose
+    workgroup count is that level's tile count (level 3 at batch 1: the latency kernel "v4", 256; level 2: 1024; level 1: 4096;
+    bench.py's batch-8 level-3 measurement: 2048)."""
     rows = []
     for path in glob.glob(os.path.join(out_dir, tag, "**", "*counter_collection.csv"), recursive=True):
         rows += [r for r in csv.DictReader(open(path)) if "warp_corr" in r["Kernel_Name"]]
@@ -33,12 +33,8 @@ def counters(tag):
     for r in rows:
         by_disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
     ids = sorted(by_disp)
-    nfwd = sum(1 for d in ids if nwg(by_disp[d][0]) == 256 and "v4" in by_disp[d][0]["Kernel_Name"])
-    if level == 3:
-        pick = [d for d in ids if nwg(by_disp[d][0]) == 256 and "v4" in by_disp[d][0]["Kernel_Name"]]
-    else:
-        cand = [d for d in ids if nwg(by_disp[d][0]) == 512 and "v3" in by_disp[d][0]["Kernel_Name"]][:2 * nfwd]
-        pick = cand[(1 if level == 1 else 0)::2]
+    tag_ = "v4" if tiles <= 512 else "v3"
+    pick = [d for d in ids if nwg(by_disp[d][0]) == tiles and tag_ in by_disp[d][0]["Kernel_Name"]]
     vals = {}
     for d in pick:
         for r in by_disp[d]:
@@ -57,9 +53,9 @@ h = hashlib.sha256()
 for rel in ("piv_liteflownet-pytorch_amd/csrc/warp_corr.hip", "piv_liteflownet-pytorch_amd/csrc/common.h"):
     h.update(open(os.path.join(ROOT, rel), "rb").read())
 no = n // s
-alg = 4 * (C * no * no + C * n * n + 2 * n * n + 49 * no * no)
+alg = 4 * (C * no * no + C * n * n + 2 * n * n + 49 * no * no) * batch
 print(json.dumps({
-    "kernel": f"{res.get('_kernel', '?')} (level {level} of PIV 1024x1024 B=1: C={C}, stride {s}, {tiles} tiles)",
+    "kernel": f"{res.get('_kernel', '?')} (level {level} of PIV 1024x1024 B={batch}: C={C}, stride {s}, {tiles} tiles)",
     "launches_averaged": len(res.get("FETCH_SIZE", {})),
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane reads; MI355X_MICROARCH.md section HBM); WRITE_SIZE exact",
