@@ -39,9 +39,11 @@ def parse():
     ap.add_argument("--model", default="piv", choices=["piv", "hui"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed warm runs of the CPU baseline (median reported)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
-                    help="fp32 = the headline path (default); fp16 = BASELINE config #5's fp16-multiplicand conv mode, reported "
-                         "under its own metric name, never as the headline")
+    ap.add_argument("--precision", default="fp32_split3", choices=["fp32_split3", "fp32_split", "fp32", "fp16"],
+                    help="how the large convolutions multiply: fp32_split3 (the library's default: fp32 operands as two fp16 pieces, "
+                         "three partial products on the fp16 matrix cores, fp32 accumulation), fp32_split (three pieces, six partial "
+                         "products, exact to 2^-32), fp32 (the fp32 matrix instruction); fp16 = BASELINE config #5's reduced-precision "
+                         "mode, reported under its own metric name, never as the headline")
     ap.add_argument("--profile-level", type=int, default=3, help="level whose warp+correlation launch is event-timed")
     return ap.parse_args()
 
@@ -113,6 +115,42 @@ def counter_traffic(name):
     if j.get("kernel_source_sha256_16") != kernel_source_hash():
         return None, f"profiles/{name} was taken on other kernel sources ({j.get('kernel_source_sha256_16')} != {kernel_source_hash()}): re-run tools/pmc_l3.sh"
     return j.get("hbm_bytes_per_launch"), f"profiles/{name}"
+
+
+DTYPE = {
+    "fp32_split3": "f32 (fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as "
+                   "two fp16 pieces: 3 partial products per fp32 product, relative product error <= 2^-21; see `arithmetic`)",
+    "fp32_split": "f32 (fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as "
+                  "three fp16 pieces: 6 partial products per fp32 product, exact to 2^-32; see `arithmetic`)",
+    "fp32": "f32",
+    "fp16": "f16 multiplicands, f32 accumulate",
+}
+
+
+def arithmetic_modes(net, i1, i2, steps, dev):
+    """The same forward under each fp32-grade conv arithmetic, timed back to back in this process (single GPU): pairs/s and the
+    largest flow difference from the fp32 matrix instruction's result."""
+    keep = net.precision
+    res, ref = {}, None
+    for mode in ("fp32", "fp32_split", "fp32_split3"):
+        net.precision = mode
+        for _ in range(3):
+            flow = net(i1, i2)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            flow = net(i1, i2)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if ref is None:
+            ref = flow.clone()
+        res[mode] = {"pairs_per_s": round(steps * i1.shape[0] / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
+                     "max_abs_px_vs_fp32_instruction": round(float((flow - ref).abs().max()), 7)}
+    net.precision = keep
+    res["what"] = ("fp32 = v_mfma_f32_32x32x2_f32 on every conv; fp32_split / fp32_split3 = stride-1 convs with >= 256x256 outputs on "
+                   "v_mfma_f32_32x32x16_f16 with fp32 operands split into 3 / 2 fp16 pieces (6 / 3 partial products, fp32 accumulate); "
+                   "layer-output error against float64 (tests/test_gpu_split.py): both splits 0.6 x the fp32 instruction's")
+    return res
 
 
 def l3_throughput_regime(dev, batch=8, launches=40):
@@ -272,20 +310,23 @@ def main():
                     "timer": "HIP start/stop events attached to the dispatch (hipExtLaunchKernelGGL) in every timed step, on the "
                              "stream the kernel runs on; event_record_pair_us = plain hipEventRecord pair around the same launch "
                              "(adds the marker packets' own cost); rocprofv3 average for the same kernel: profiles/"}
+        fp32_grade = args.precision != "fp16"
         out = {
             "metric": (("PIV" if args.model == "piv" else "LiteFlowNet (Hui weights layout)") +
-                       (f" image-pairs/s at {S}x{S} fp32" if args.precision == "fp32" else
+                       (f" image-pairs/s at {S}x{S} fp32" if fp32_grade else
                         f" image-pairs/s at {S}x{S}, fp16-multiplicand conv mode (BASELINE config #5 variant; not the fp32 headline)")),
             "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16 multiplicands, f32 accumulate", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": f"{'PIV-LiteFlowNet-en' if args.model == 'piv' else 'LiteFlowNet'} forward, batch {B}/GPU, "
-                                   f"{S}x{S} synthetic PIV pair, " + ("fp32 (BASELINE configs[1])" if args.precision == "fp32" else "fp16-multiplicand convs"),
+                                   f"{S}x{S} synthetic PIV pair, " + ("fp32 (BASELINE configs[1])" if fp32_grade else "fp16-multiplicand convs"),
+                       "conv_arithmetic": args.precision,
                        "pairs_per_step_per_gpu": B, "weights": "generated (pivlfn.synth seed 0)",
                        "multi_gpu": "pairs sharded over ranks, async RCCL all-gather of flows per step" if world > 1 else "single GPU"},
             "roofline": roof,
             "whole_net": {"conv_tflops": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
                           "fp32_mfma_peak_tflops": 157.3,
+                          # against the fp32 instruction's peak: above 1 means the split path beats what that instruction can do at all
                           "compute_frac": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None,
                           # layer-boundary bytes of the reference's graph (in + out + weights of every conv, fp32)
                           "layer_boundary_gb_per_pair": 16.57 if (args.model == 'piv' and S == 1024) else None,
@@ -302,6 +343,8 @@ def main():
                                       "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2]}
         if world == 1 and args.model == "piv" and S == 1024:
             out["roofline_batch8"] = l3_throughput_regime(dev)
+        if world == 1 and fp32_grade:
+            out["arithmetic"] = arithmetic_modes(net, i1, i2, min(args.steps, 10), dev)
         if not args.no_cpu_baseline and world == 1:
             ref, cb = cpu_baseline(args.model, S, wts, i1c, i2c, runs=args.cpu_runs)
             out["cpu_baseline"] = cb

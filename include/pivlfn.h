@@ -105,6 +105,17 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
  * (correlation, warps, flow heads, regularisation tail) is fp32 in both modes. */
 #define PIVLFN_PRECISION_F32 0
 #define PIVLFN_PRECISION_F16 1
+/* PIVLFN_PRECISION_F32_SPLIT: fp32 results from the fp16 matrix cores.  Every fp32 operand is split exactly into three fp16
+ * pieces (11 + 11 + 2 significand bits at scales 1, 2^-11, 2^-22) and each product is formed from six exact fp16 x fp16
+ * products accumulated in fp32; what is dropped is below 2^-32 of a product, 256 x under the rounding of an fp32 fma
+ * (csrc/conv_split.hip; tests/test_gpu_split.py measures the error against float64 next to the fp32 instruction's).
+ * Applies to the stride-1 convolutions with an output grid of at least 64 x 64; everything else runs as in F32. */
+#define PIVLFN_PRECISION_F32_SPLIT 2
+/* PIVLFN_PRECISION_F32_SPLIT3: the same with two pieces per operand and the three leading partial products (h.h, h.m, m.h):
+ * a product carries a relative error of at most 2^-21 (typically 2^-23.5, about one fp32 ulp on each operand); measured against
+ * float64 the layer outputs are as accurate as SPLIT's and more accurate than the fp32 instruction's (fewer roundings in the
+ * accumulation), at half the matrix work. */
+#define PIVLFN_PRECISION_F32_SPLIT3 3
 int pivlfn_set_precision(pivlfn_net *net, int precision);
 
 /* Number of floats `levels` must hold for pivlfn_forward. */
@@ -127,6 +138,11 @@ int pivlfn_conv2d_nhwc(const pivlfn_conv *conv, const float *x, int x_stride, fl
  * or fp16 (y_is_f16).  No residual input. */
 int pivlfn_conv2d_nhwc_f16(const pivlfn_conv *conv, const void *x, int x_stride, int x_is_f16, void *y, int y_stride,
                            int y_is_f16, int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, void *stream);
+
+/* The same layer (stride 1, no residual) on the split-operand kernel of PIVLFN_PRECISION_F32_SPLIT (terms = 6) or
+ * PIVLFN_PRECISION_F32_SPLIT3 (terms = 3): fp32 x, fp32 y. */
+int pivlfn_conv2d_nhwc_split(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                             int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, int terms, void *stream);
 
 /* The 32 -> 2 channel k x k flow head (conv_M.6 / conv_S.6) on its dedicated kernel: x [B,H,W,32], res4/out4 [B,H,W,4]. */
 int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W,

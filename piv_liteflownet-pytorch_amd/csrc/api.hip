@@ -52,6 +52,8 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
 int conv_forward_h(const pivlfn_conv *c, const void *x, int x_stride, int x_f16, void *y, int y_stride, int y_f16,
                    int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, hipStream_t st);
 int net_set_precision(pivlfn_net *net, int precision);
+int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride,
+                   int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, int terms, hipStream_t st);
 int conv_head_forward(const pivlfn_conv *c, const float *x, const float *res4, float *out4, int B, int H, int W, hipStream_t st);
 
 }  // namespace pivlfn
@@ -150,6 +152,12 @@ int pivlfn_conv2d_nhwc_f16(const pivlfn_conv *conv, const void *x, int x_stride,
                            int y_is_f16, int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, void *stream)
 {
     return conv_forward_h(conv, x, x_stride, x_is_f16, y, y_stride, y_is_f16, B, H, W, stride, pad_y, pad_x, leaky, (hipStream_t)stream);
+}
+
+int pivlfn_conv2d_nhwc_split(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                             int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, int terms, void *stream)
+{
+    return conv_forward_x(conv, x, x_stride, y, y_stride, B, H, W, stride, pad_y, pad_x, leaky, terms, (hipStream_t)stream);
 }
 
 int pivlfn_set_precision(pivlfn_net *net, int precision) { return net_set_precision(net, precision); }

@@ -137,6 +137,23 @@ struct ConvParamsH {
     unsigned long long *stamps;   // tools only: per-workgroup phase times (s_memtime ticks), 8 per workgroup; nullptr in production
 };
 int launch_conv_h(const ConvParamsH &p, hipStream_t st);
+// ---- fp32 by exact fp16 operand splitting (conv_split.hip): fp32 sources and output, K chunks of 16 channels ------------
+struct ConvParamsX {
+    ConvSeg seg[3];
+    int nseg;
+    const void *wpk;    // fp16 pieces [nchunk][KH*KW][3][2][cout_pad][8]
+    const float *bias;  // [cout_pad]
+    float *out;         // NHWC fp32
+    int out_stride, cout_store, cout_pad;
+    float out_scale;    // 2^-k: undoes the power-of-two scale of the packed weights
+    int terms;          // partial products per product: 6 (exact to 2^-32) or 3 (h.h, h.m, m.h: 2^-21)
+    int B, H, W, Ho, Wo;
+    int KH, KW, S, padY, padX;
+    int nchunk, lrelu;
+    int dbg;            // ablation mask for tools/bench_ops.py (0 in production): 1 no MFMAs, 2 no global loads, 4 no LDS commit
+};
+int launch_conv_x(const ConvParamsX &p, hipStream_t st);
+bool conv_split_supports(int KH, int KW, int S, int cout_pad);
 // 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device
 int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                      int k, hipStream_t st);

@@ -1,0 +1,382 @@
+// fp32 convolution on the fp16 matrix cores by exact operand splitting.
+//
+// gfx950's fp32 matrix instruction (v_mfma_f32_32x32x2_f32, conv_mfma.hip) runs at 1/16 of the rate of
+// v_mfma_f32_32x32x16_f16.  An fp32 number is the exact sum of three fp16 numbers at staggered scales,
+//
+//     x = h + m * 2^-11 + l * 2^-22,     h = rn16(x),  m = rn16((x - h) * 2^11),  l = rn16(((x - h) * 2^11 - m) * 2^11)
+//
+// (11 + 11 + 2 significand bits; every subtraction is exact in fp32), so a product of two fp32 numbers is the sum of nine
+// fp16 x fp16 products, each exact in the fp32 the matrix core accumulates in.  Six of them carry everything above 2^-33 of the
+// product:  h.h | h.m 2^-11, m.h 2^-11 | m.m 2^-22, h.l 2^-22, l.h 2^-22;  the three dropped ones are <= 2^-32 relative -- 256 x
+// below the rounding an fp32 fma chain itself commits per step.  The sum over K and over the six terms is accumulated in fp32
+// by the instruction, exactly as the fp32 instruction does for its products.  6 fp16 MFMAs replace 8 fp32 MFMAs of 1/16 the
+// rate: 2.67 x the matrix throughput at fp32 accuracy (tests/test_gpu_split.py: the error against a float64 convolution is that
+// of conv_mfma.hip).  Inputs, outputs, bias and activation are fp32; |x| must stay below 65504 (fp16 range of the head piece).
+//
+// Scales.  The 2^-11 / 2^-22 factors have to live in an operand (one accumulator).  Activation magnitudes are not known, so
+// the activation pieces stay at their natural scale (h, m, l all of the magnitude of x: no fp16 underflow) and the factors go
+// to the weight side, whose magnitudes are known at load time: a layer's weights are scaled by a power of two so that max |w|
+// lands in [2^13, 2^14) and the result is scaled back (exactly) in the epilogue.  Per weight the kernel multiplies
+//     h by  P0 = bh,  P1 = bm 2^-11,  P2 = bl 2^-22        (three stored pieces)
+//     m by  P0 2^-11, P1 2^-11                              (derived in registers: v_pk_mul_f16 by a power of two)
+//     l by  P0 2^-22
+// Pieces that fall below 2^-14 become fp16 subnormals (or zero); what they then lose is below 2^-25 of the *largest* weight
+// times the activation -- 2^-35 of a typical sum.
+//
+// Shape: conv_f16.hip's (workgroup = 4 waves = (4*MT rows x 32 px) x (32*NT channels), K chunk = 16 channels = one MFMA
+// k-step per tap and piece pair, patch staged once per chunk, next chunk prefetched global -> registers under the MFMAs),
+// except that the weight slab of a chunk (3 pieces) is staged one kernel row at a time, so that two workgroups fit a CU
+// and alternate on the matrix pipe while the other splits and stages:
+//   LDS pixel record = 3 pieces x 16 halfs + 8 halfs of padding = 112 bytes (7 * pixel mod 16 visits all sixteen 16-byte
+//   slots of a 256-byte bank row: conflict-free ds_read_b128); weights [kx][piece][k-half][channel][8].
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "common.h"
+
+namespace pivlfn {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+// x -> (h, m, l) with x = h + m 2^-11 + l 2^-22 exactly (|x| < 65504, pieces not subnormal)
+__device__ __forceinline__ void split3(float x, _Float16 &h, _Float16 &m, _Float16 &l)
+{
+    h = (_Float16)x;
+    const float r1 = (x - (float)h) * 2048.f;
+    m = (_Float16)r1;
+    const float r2 = (r1 - (float)m) * 2048.f;
+    l = (_Float16)r2;
+}
+
+// TERMS = 6: all six partial products (three pieces per operand).  TERMS = 3: h.h, h.m, m.h only (two pieces per operand, 80-byte
+// pixel records): each product then carries a relative error of up to 2^-21 (typically 2^-23.5) instead of 2^-32.
+template <int TERMS, int MT, int NT, int PM, int WM, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX p)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 xsmem[];
+    constexpr int NP = TERMS == 6 ? 3 : 2;       // pieces per operand
+    constexpr int XPITCH = NP * 16 + 8;          // halfs per staged pixel (112 / 80 bytes: 7 or 5 sixteen-byte slots, odd -> conflict-free)
+    constexpr int BN = NT * 32;
+    constexpr int TH = 4 * MT;
+    const int PH = (TH - 1) * p.S + p.KH;
+    const int PW = 31 * p.S + p.KW;
+    const int npix = PH * PW;
+    _Float16 *patch = xsmem;
+    _Float16 *wts = xsmem + npix * XPITCH;                                   // [KW][NP][2][BN][8]
+    float *lbias = reinterpret_cast<float *>(wts + p.KW * NP * 2 * BN * 8); // this workgroup's BN biases
+
+    const int tiles_x = (p.Wo + 31) >> 5;
+    const int tiles_y = (p.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int n0 = blockIdx.y * BN;
+    const int x0 = tx * 32, y0 = ty * TH;
+    const int ix0 = x0 * p.S - p.padX, iy0 = y0 * p.S - p.padY;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, hh = lane >> 5;
+    const int sub = tid & 1;
+
+    if (tid < BN) lbias[tid] = p.bias[n0 + tid];       // visible after the first barrier of the K loop
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    int abase[MT];      // half offset of this lane's pixel operand (piece 0) for tap (0,0)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = ((wave * MT + m) * p.S * PW + row * p.S) * XPITCH + hh * 8;
+    const int bbase = (hh * BN + row) * 8;
+
+    // staging items: patch item i = pixel (tid>>1) + 128*i, channel half `sub` (channels 4 sub .. +3 and 8 + 4 sub .. +3);
+    // weight item i = 16-byte unit tid + 256*i of the row's [KW][3][2][BN] units
+    int poff[PM];       // pixel index inside the source, -1 = outside the image, -2 = no item
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+        const int pix = (tid >> 1) + 128 * i;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        poff[i] = pix >= npix ? -2 : ((iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (b * p.H + iy) * p.W + ix : -1);
+    }
+    const int nw = p.KW * NP * 2 * BN;
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + n0;
+    const size_t wrow = (size_t)p.KW * 6 * p.cout_pad;      // 16-byte units per (chunk, ky) in the packed weights (always 3 pieces)
+
+    f32x4 pr[2 * PM], wr[WM];
+    int seg = 0, c0 = 0;
+    const float *sp = p.seg[0].ptr;
+    int scl = p.seg[0].cload, sst = p.seg[0].stride;
+
+#define X_LOAD_PATCH()                                                                            \
+    do {                                                                                          \
+        if (p.dbg & 2) break;                                                                     \
+        const bool ok0_ = c0 + 4 * sub < scl, ok1_ = c0 + 8 + 4 * sub < scl;                      \
+        _Pragma("unroll") for (int i = 0; i < PM; ++i) {                                          \
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};                           \
+            if (poff[i] >= 0) {                                                                   \
+                const float *q_ = sp + (size_t)poff[i] * sst + c0 + 4 * sub;                      \
+                if (ok0_) v0 = *reinterpret_cast<const f32x4 *>(q_);                              \
+                if (ok1_) v1 = *reinterpret_cast<const f32x4 *>(q_ + 8);                          \
+            }                                                                                     \
+            pr[2 * i] = v0;                                                                       \
+            pr[2 * i + 1] = v1;                                                                   \
+        }                                                                                         \
+    } while (0)
+#define X_LOAD_W(ROWIDX)                                                                          \
+    do {                                                                                          \
+        if (p.dbg & 2) break;                                                                     \
+        const f32x4 *wc_ = wsrc + (size_t)(ROWIDX)*wrow;                                          \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                          \
+            const int idx_ = tid + 256 * i;                                                       \
+            const int r_ = idx_ / BN;       /* staged row (kx * NP + piece) * 2 + k-half */        \
+            const int src_ = NP == 3 ? r_ : (r_ / 4) * 6 + (r_ % 4);                               \
+            if (idx_ < nw) wr[i] = wc_[src_ * p.cout_pad + (idx_ % BN)];                          \
+        }                                                                                         \
+    } while (0)
+
+    const h8 k11 = {(_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f,
+                    (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f};
+    const h8 k22 = {(_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f,
+                    (_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f};
+
+    X_LOAD_PATCH();
+    X_LOAD_W(0);
+    const int nrows = p.nchunk * p.KH;      // (chunk, ky) phases
+    int phase = 0;
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        // registers -> LDS: split this chunk's fp32 patch into its three fp16 pieces (the previous chunk's last barrier has
+        // been passed by every wave: the patch buffer is free)
+        if (!(p.dbg & 4)) {
+#pragma unroll
+            for (int i = 0; i < PM; ++i)
+                if (poff[i] != -2) {
+                    _Float16 *d = patch + ((tid >> 1) + 128 * i) * XPITCH + 4 * sub;
+                    h4 ph[2], pm[2], pl[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f32x4 v = pr[2 * i + e];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            _Float16 a, bq, c;
+                            split3(v[j], a, bq, c);
+                            ph[e][j] = a; pm[e][j] = bq; pl[e][j] = c;
+                        }
+                    }
+                    *reinterpret_cast<h4 *>(d) = ph[0];
+                    *reinterpret_cast<h4 *>(d + 8) = ph[1];
+                    *reinterpret_cast<h4 *>(d + 16) = pm[0];
+                    *reinterpret_cast<h4 *>(d + 24) = pm[1];
+                    if (NP == 3) {
+                        *reinterpret_cast<h4 *>(d + 32) = pl[0];
+                        *reinterpret_cast<h4 *>(d + 40) = pl[1];
+                    }
+                }
+        }
+        for (int ky = 0; ky < p.KH; ++ky, ++phase) {
+            if (!(p.dbg & 4)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    if (tid + 256 * i < nw) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+            }
+            __syncthreads();
+            if (ky == 0 && chunk + 1 < p.nchunk) {
+                c0 += 16;
+                if (c0 >= scl) {
+                    ++seg;
+                    c0 = 0;
+                    sp = p.seg[seg].ptr;
+                    scl = p.seg[seg].cload; sst = p.seg[seg].stride;
+                }
+                X_LOAD_PATCH();
+            }
+            if (phase + 1 < nrows) X_LOAD_W(phase + 1);
+            if (!(p.dbg & 1)) {
+                for (int kx = 0; kx < p.KW; ++kx) {
+                    const int toff = (ky * PW + kx) * XPITCH;
+                    h8 a[MT][NP];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) a[m][j] = *reinterpret_cast<const h8 *>(patch + abase[m] + toff + j * 16);
+                    const _Float16 *wk = wts + kx * NP * 2 * BN * 8 + bbase;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const h8 w0 = *reinterpret_cast<const h8 *>(wk + n * 256);
+                        const h8 w1 = *reinterpret_cast<const h8 *>(wk + 2 * BN * 8 + n * 256);
+                        const h8 w0m = w0 * k11;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {      // A = channels, B = pixels; smallest terms first
+                            if (NP == 3) {
+                                const h8 w2 = *reinterpret_cast<const h8 *>(wk + 4 * BN * 8 + n * 256);
+                                const h8 w1m = w1 * k11, w0l = w0 * k22;
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l, a[m][NP - 1], acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, a[m][0], acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1m, a[m][1], acc[m][n], 0, 0, 0);
+                            }
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0m, a[m][1], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, a[m][0], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, a[m][0], acc[m][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#undef X_LOAD_PATCH
+#undef X_LOAD_W
+
+    // Epilogue: lane&31 = pixel, registers 4g..4g+3 = channels 8g + 4*hh + {0..3} (the D layout of the 32x32 instructions).
+    {
+        const int ox = x0 + row;
+        const bool interior = x0 + 32 <= p.Wo && y0 + TH <= p.Ho && n0 + BN <= p.cout_store;
+        const float sc = p.out_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + wave * MT + m;
+            const bool pix_ok = interior || (oy < p.Ho && ox < p.Wo);
+            const size_t pix = (size_t)(b * p.Ho + (oy < p.Ho ? oy : 0)) * p.Wo + (ox < p.Wo ? ox : 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n0 + n * 32 + 8 * g + 4 * hh;
+                    if (!pix_ok || (!interior && ch >= p.cout_store)) continue;
+                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(lbias + (ch - n0));
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * g + j] * sc + bq[j];     // sc is a power of two: exact
+                    if (p.lrelu) {
+                        v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                    }
+                    *reinterpret_cast<f32x4 *>(p.out + pix * p.out_stride + ch) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TERMS, int MT, int NT, int PM, int WM, int OCC>
+static int launch_x(const ConvParamsX &p, hipStream_t st)
+{
+    constexpr int TH = 4 * MT, BN = NT * 32, NP = TERMS == 6 ? 3 : 2, XPITCH = NP * 16 + 8;
+    const int PH = (TH - 1) * p.S + p.KH, PW = 31 * p.S + p.KW;
+    const size_t lds = ((size_t)PH * PW * XPITCH + (size_t)p.KW * NP * 2 * BN * 8) * sizeof(_Float16) + BN * sizeof(float);
+    PIV_REQUIRE(lds * OCC <= 160 * 1024, "conv_split: LDS tile of %zu bytes x %d exceeds 160 KiB (k=%dx%d s=%d)", lds, OCC, p.KH, p.KW, p.S);
+    PIV_REQUIRE(PH * PW * 2 <= 256 * PM && p.KW * NP * 2 * BN <= 256 * WM, "conv_split: internal staging bound exceeded");
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_split_kernel<TERMS, MT, NT, PM, WM, OCC>), 160 * 1024)) return rc;
+    const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
+    dim3 grid(tiles, p.cout_pad / BN);
+    hipLaunchKernelGGL((conv_split_kernel<TERMS, MT, NT, PM, WM, OCC>), grid, dim3(256), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+// Which layers the kernel takes (net.hip asks before routing): stride 1, at most 7 taps per kernel row, 16-byte granular sources.
+bool conv_split_supports(int KH, int KW, int S, int cout_pad)
+{
+    if (S != 1 || KW > 7 || KH > 7 || cout_pad % 32 != 0) return false;
+    const int PH = 7 + KH, PW = 31 + KW;                 // 8-row tile
+    const int bn = cout_pad % 64 == 0 ? 64 : 32;
+    const size_t lds = ((size_t)PH * PW * 56 + (size_t)KW * 6 * bn * 8) * 2 + bn * 4;      // the six-term layout, the larger one
+    return lds * 2 <= 160 * 1024 && PH * PW * 2 <= 256 * 5 && KW * 6 * bn <= 256 * 11;
+}
+
+int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
+{
+    ConvParamsX p = p_in;
+    p.dbg = PIV_KNOB(3);
+    PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.nchunk >= 1, "conv_split: bad segment description");
+    PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0, "conv_split: bad output channel counts");
+    for (int i = 0; i < p.nseg; ++i)
+        PIV_REQUIRE(p.seg[i].ptr && p.seg[i].cload % 4 == 0 && p.seg[i].stride % 4 == 0, "conv_split: source %d must be 16-byte granular", i);
+    PIV_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.B > 0, "conv_split: empty output");
+    PIV_REQUIRE(conv_split_supports(p.KH, p.KW, p.S, p.cout_pad), "conv_split: unsupported geometry k=%dx%d s=%d", p.KH, p.KW, p.S);
+    if (PIV_KNOB(1) & 65536) p.terms = 3;     // tools: three-term products whatever the caller asked for
+    const bool wide = p.KW > 3;                       // 1 x k / k x k rows of 5 or 7 taps: the larger weight-row class
+    const bool tall = (7 + p.KH) * (31 + p.KW) * 2 > 256 * 3;
+    if (p.terms == 3) {
+        if (p.cout_pad % 128 == 0 && !wide && !tall && !(PIV_KNOB(1) & 131072)) return launch_x<3, 2, 4, 3, 6, 2>(p, st);
+        if (p.cout_pad % 64 == 0) {
+            if (wide) return launch_x<3, 2, 2, 5, 7, 2>(p, st);
+            return tall ? launch_x<3, 2, 2, 5, 3, 2>(p, st) : launch_x<3, 2, 2, 3, 3, 3>(p, st);
+        }
+        if (wide) return launch_x<3, 2, 1, 5, 4, 2>(p, st);
+        return tall ? launch_x<3, 2, 1, 5, 2, 2>(p, st) : launch_x<3, 2, 1, 3, 2, 3>(p, st);
+    }
+    if (p.cout_pad % 64 == 0) {
+        if (wide) return launch_x<6, 2, 2, 5, 11, 2>(p, st);
+        return tall ? launch_x<6, 2, 2, 5, 5, 2>(p, st) : launch_x<6, 2, 2, 3, 5, 2>(p, st);
+    }
+    if (wide) return launch_x<6, 2, 1, 5, 6, 2>(p, st);
+    return tall ? launch_x<6, 2, 1, 5, 3, 2>(p, st) : launch_x<6, 2, 1, 3, 3, 2>(p, st);
+}
+
+static unsigned short f16_bits(float v)
+{
+    const _Float16 h = (_Float16)v;
+    unsigned short b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+
+// OIHW fp32 weights -> fp16 pieces [chunk][tap][piece][k-half][cout_pad][8]; chunk = 16 staged input channels of one source.
+// *out_scale = 2^-k, the factor that undoes the power-of-two weight scale (max |w| 2^k in [2^13, 2^14)).
+void pack_conv_x(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
+                 std::vector<unsigned short> &pk, int *nchunk_out, float *out_scale)
+{
+    const int cp = (cout + 31) / 32 * 32;
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * taps; ++i)
+        if (std::isfinite(w[i])) wmax = std::fmax(wmax, std::fabs(w[i]));
+    int e = 0;
+    if (wmax > 0.f) {
+        std::frexp(wmax, &e);        // wmax = f 2^e, f in [0.5, 1)  ->  wmax 2^(14-e) in [2^13, 2^14)
+        e = 14 - e;
+    }
+    e = std::max(-100, std::min(100, e));
+    const double s = std::ldexp(1.0, e);
+    *out_scale = (float)std::ldexp(1.0, -e);
+    int nchunk = 0;
+    for (int sg = 0; sg < nseg; ++sg) nchunk += (cload[sg] + 15) / 16;
+    pk.assign((size_t)nchunk * taps * 6 * cp * 8, 0);
+    int chunk = 0, run = 0;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int off = coff[sg] >= 0 ? coff[sg] : run;
+        for (int c0 = 0; c0 < cload[sg]; c0 += 16, ++chunk)
+            for (int t = 0; t < taps; ++t)
+                for (int kb = 0; kb < 2; ++kb)
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = c0 + 8 * kb + j;
+                        if (c >= creal[sg]) continue;
+                        for (int n = 0; n < cout; ++n) {
+                            const double bw = (double)w[((size_t)n * cin + off + c) * taps + t] * s;       // exact
+                            const float bh = (float)(_Float16)(float)bw;
+                            const double r1 = (bw - (double)bh) * 2048.0;                                   // exact
+                            const float bm = (float)(_Float16)(float)r1;
+                            const double r2 = (r1 - (double)bm) * 2048.0;                                   // exact
+                            const float bl = (float)(_Float16)(float)r2;
+                            const float piece[3] = {bh, bm * 0x1p-11f, bl * 0x1p-22f};
+                            for (int q = 0; q < 3; ++q)
+                                pk[(((((size_t)chunk * taps + t) * 3 + q) * 2 + kb) * cp + n) * 8 + j] = f16_bits(piece[q]);
+                        }
+                    }
+        run += creal[sg];
+    }
+    *nchunk_out = nchunk;
+}
+
+}  // namespace pivlfn

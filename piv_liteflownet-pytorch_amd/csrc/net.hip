@@ -21,12 +21,17 @@ static const size_t KSPLIT_FLOATS = (size_t)8 * 128 * 128 * 32;
 
 void pack_conv_h(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
                  std::vector<unsigned short> &pk, int *nchunk_out);      // conv_f16.hip
+void pack_conv_x(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
+                 std::vector<unsigned short> &pk, int *nchunk_out, float *out_scale);      // conv_split.hip
 
 struct ConvW {
     float *wpk = nullptr, *bias = nullptr;
     int cout = 0, cout_pad = 0, KH = 0, KW = 0, nchunk = 0, tail = 0;
     void *wpk_h = nullptr;         // fp16 packing for conv_f16.hip (K chunks of 16 channels)
     int nchunk_h = 0;
+    void *wpk_x = nullptr;         // three-piece fp16 packing for conv_split.hip (fp32 by exact splitting); nullptr = unsupported geometry
+    int nchunk_x = 0;
+    float scale_x = 1.f;           // 2^-k undoing the weight scale of wpk_x
 };
 
 struct LevelW {
@@ -56,7 +61,7 @@ struct pivlfn_net {
     int nstack = 3;                // hidden conv_M / conv_S layers: 3 = LiteFlowNet (src/models.py:154-163), 5 = LiteFlowNet2 (:487-500)
     int width[5] = {128, 64, 32, 0, 0};
     float mean[6];
-    int precision = 0;             // 0 = fp32 everywhere (default); 1 = fp16 multiplicands in the conv stacks (conv_f16.hip)
+    int precision = 3;             // PIVLFN_PRECISION_*: 0 fp32 instruction, 1 fp16 multiplicands, 2 / 3 fp32 by operand splitting (default 3)
     pivlfn::ConvW netc[10];
     pivlfn::ConvW ext[3];          // index by level (1,2)
     pivlfn::LevelW lv[7];
@@ -156,6 +161,17 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         net->allocs.push_back(d);
         PIV_CHECK_HIP(hipMemcpy(d, ph.data(), ph.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         out->wpk_h = d;
+    }
+    if (conv_split_supports(kh, kw, 1, cp)) {   // the split-operand packing of the same layer (fp32 on the fp16 matrix cores)
+        std::vector<int> cr, cl, co;
+        for (auto &sg : segs) { cr.push_back(sg.creal); cl.push_back(sg.cload); co.push_back(sg.coff); }
+        std::vector<unsigned short> px;
+        pack_conv_x(w->data, cout, cin, taps, cr.data(), cl.data(), co.data(), (int)segs.size(), px, &out->nchunk_x, &out->scale_x);
+        void *d = nullptr;
+        PIV_CHECK_HIP(hipMalloc(&d, px.size() * sizeof(unsigned short)));
+        net->allocs.push_back(d);
+        PIV_CHECK_HIP(hipMemcpy(d, px.data(), px.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        out->wpk_x = d;
     }
     return upload(net, bias, &out->bias);
 }
@@ -488,6 +504,23 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         return launch_conv_h(q, st);
     }
     PIV_REQUIRE(!in16 && !out16, "internal: fp16 activations routed to the fp32 conv kernel");
+    // split modes: every residual-free stride-1 conv with an output grid of at least 256x256 per image runs on the fp16 matrix
+    // cores with split fp32 operands (conv_split.hip); coarser grids have too few 8-row tiles for its two workgroups per CU and
+    // stay on the fp32 instruction kernel (measured at 1024^2, 512^2 and 256^2: tools/split_threshold.py).  Per image: the
+    // choice never depends on the batch.
+    if (t_precision >= 2 && !res && S == 1 && cw.wpk_x && (long)Ho * Wo >= (PIV_KNOB(11) ? PIV_KNOB(11) : 256 * 256)) {
+        ConvParamsX q;
+        memset(&q, 0, sizeof(q));
+        int i = 0;
+        for (auto &sg : segs) q.seg[i++] = sg;
+        q.nseg = i;
+        q.wpk = cw.wpk_x; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
+        q.cout_pad = cw.cout_pad; q.out_scale = cw.scale_x; q.terms = t_precision == 3 ? 3 : 6;
+        q.B = B; q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
+        q.KH = cw.KH; q.KW = cw.KW; q.S = S; q.padY = padY; q.padX = padX;
+        q.nchunk = cw.nchunk_x; q.lrelu = lrelu;
+        return launch_conv_x(q, st);
+    }
     ConvParams p;
     memset(&p, 0, sizeof(p));
     int i = 0;
@@ -507,7 +540,7 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
 
 int net_set_precision(pivlfn_net *net, int precision)
 {
-    PIV_REQUIRE(net && (precision == 0 || precision == 1), "set_precision: 0 (fp32) or 1 (fp16 multiplicands) expected");
+    PIV_REQUIRE(net && precision >= 0 && precision <= 3, "set_precision: 0 (fp32 instruction), 1 (fp16 multiplicands), 2 (fp32 by exact splitting) or 3 (three-term splitting) expected");
     net->precision = precision;
     return PIVLFN_OK;
 }
@@ -533,6 +566,30 @@ int conv_forward_h(const pivlfn_conv *c, const void *x, int x_stride, int x_f16,
     q.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
     q.nchunk = c->cw.nchunk_h; q.lrelu = leaky;
     return launch_conv_h(q, st);
+}
+
+// Standalone layer on the split-operand kernel (tests, tools): fp32 in, fp32 out.
+int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride,
+                   int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, int terms, hipStream_t st)
+{
+    PIV_REQUIRE(c && x && y, "conv2d_split: null argument");
+    PIV_REQUIRE(terms == 6 || terms == 3, "conv2d_split: terms=%d (6 or 3 partial products per product)", terms);
+    PIV_REQUIRE(c->cw.wpk_x && stride == 1, "conv2d_split: this layer's geometry (k=%dx%d, stride %d) is not covered by the split kernel", c->cw.KH, c->cw.KW, stride);
+    PIV_REQUIRE(x_stride % 4 == 0 && x_stride >= rup(c->cin, 4), "conv2d_split: x_stride=%d must be a multiple of 4 and >= %d", x_stride, rup(c->cin, 4));
+    PIV_REQUIRE(y_stride % 4 == 0 && y_stride >= c->cw.cout, "conv2d_split: y_stride=%d must be a multiple of 4 and >= cout=%d", y_stride, c->cw.cout);
+    PIV_REQUIRE(pad_y >= 0 && pad_x >= 0 && H + 2 * pad_y >= c->cw.KH && W + 2 * pad_x >= c->cw.KW, "conv2d_split: bad geometry");
+    ConvParamsX q;
+    memset(&q, 0, sizeof(q));
+    q.seg[0] = ConvSeg{x, rup(c->cin, 4), x_stride};
+    q.nseg = 1;
+    q.wpk = c->cw.wpk_x; q.bias = c->cw.bias; q.out = y; q.out_stride = y_stride;
+    q.cout_store = std::min(rup(c->cw.cout, 4), y_stride);
+    q.cout_pad = c->cw.cout_pad; q.out_scale = c->cw.scale_x; q.terms = terms;
+    q.B = B; q.H = H; q.W = W; q.KH = c->cw.KH; q.KW = c->cw.KW; q.S = 1; q.padY = pad_y; q.padX = pad_x;
+    q.Ho = H + 2 * pad_y - c->cw.KH + 1;
+    q.Wo = W + 2 * pad_x - c->cw.KW + 1;
+    q.nchunk = c->cw.nchunk_x; q.lrelu = leaky;
+    return launch_conv_x(q, st);
 }
 
 int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels, int B, int H, int W,

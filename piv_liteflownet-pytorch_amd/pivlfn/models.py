@@ -84,22 +84,29 @@ class LiteFlowNet(torch.nn.Module):
         self._handle = None
         self._handle_key = None
         self._ws = None
-        self._precision = "fp32"
+        self._precision = "fp32_split3"
 
-    # -- precision of the conv stacks (BASELINE config #5) ------------------------------------------------
+    # -- precision of the conv stacks ---------------------------------------------------------------------
+    _PRECISIONS = {"fp32": 0, "fp16": 1, "fp32_split": 2, "fp32_split3": 3}
+
     @property
     def precision(self) -> str:
-        """'fp32' (default, the mode all fp32 parity statements refer to) or 'fp16' (fp16 multiplicands with fp32
-        accumulation in every convolution whose output grid is at least 64x64; everything else stays fp32)."""
+        """How the large convolutions multiply (everything else -- correlation, warps, heads, small levels -- is fp32 throughout):
+        'fp32_split3' (default) fp32 operands as two fp16 pieces each, the three leading partial products on the fp16 matrix
+                      cores, fp32 accumulation: products good to 2^-21 (typically 2^-23.5), layer outputs as close to float64 as
+                      'fp32_split' and closer than 'fp32' (csrc/conv_split.hip, tests/test_gpu_split.py);
+        'fp32_split'  three pieces, six partial products: products exact to 2^-32;
+        'fp32'        the fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32), 1/16 of the fp16 instruction's rate;
+        'fp16'        operands rounded to fp16 (BASELINE config #5): reduced precision, its own tolerance."""
         return self._precision
 
     @precision.setter
     def precision(self, value: str) -> None:
-        if value not in ("fp32", "fp16"):
-            raise ValueError("precision must be 'fp32' or 'fp16'")
+        if value not in self._PRECISIONS:
+            raise ValueError("precision must be 'fp32', 'fp32_split', 'fp32_split3' or 'fp16'")
         self._precision = value
         if self.__dict__.get("_handle") is not None:
-            _lib.check(_lib.load().pivlfn_set_precision(self._handle, 1 if value == "fp16" else 0), "set_precision")
+            _lib.check(_lib.load().pivlfn_set_precision(self._handle, self._PRECISIONS[value]), "set_precision")
 
     # -- parameter tree --------------------------------------------------------------------------------
     def _fan_in_of_bias(self, name: str) -> int:
@@ -157,8 +164,7 @@ class LiteFlowNet(torch.nn.Module):
             _lib.check(lib.pivlfn_create(arr, len(host), self.starting_scale, self.lowest_level, mean, ctypes.byref(h)),
                        "LiteFlowNet: weight upload")
         self._handle, self._handle_key = h, key
-        if self._precision == "fp16":
-            _lib.check(lib.pivlfn_set_precision(h, 1), "set_precision")
+        _lib.check(lib.pivlfn_set_precision(h, self._PRECISIONS[self._precision]), "set_precision")
         return h
 
     def _release(self):

@@ -84,6 +84,7 @@ def test_fp16_mode_end_point_error(model, size, dev):
     i1 = torch.from_numpy(synth.to_input(a))[None].to(dev)
     i2 = torch.from_numpy(synth.to_input(b))[None].to(dev)
     net = pivlfn.Network(model=model, params=synth.generate_weights(model, 0)).to(dev).eval()
+    net.precision = "fp32"
     f32 = net(i1, i2).cpu().numpy()
     net.precision = "fp16"
     assert net.precision == "fp16"

@@ -1,0 +1,185 @@
+"""GPU: fp32 convolution on the fp16 matrix cores by operand splitting (csrc/conv_split.hip): precision 'fp32_split3' (the
+default: two fp16 pieces per operand, three partial products) and 'fp32_split' (three pieces, six partial products).
+
+The statements, for both:
+  * per layer, against a float64 convolution of the SAME fp32 inputs and weights, the split kernel's error is of the size of the
+    fp32-instruction kernel's (fp32 summation-order noise; the split adds < 2^-32 / < 2^-21 per product) -- the bar is the fp32
+    kernel's own bar (2e-5 of max|out|), the mean error may not exceed twice the fp32 instruction's (measured: 0.6 x), and the
+    two are printed next to each other;
+  * the accuracy does not depend on the magnitudes: weights of 1e-6 and 1e+3, activations of 1e-4 and 1e+3, mixed magnitudes
+    inside one layer (fp16 pieces would underflow / overflow if the scales were not handled);
+  * end to end the mode meets the fp32 tolerance against the oracle and the reference's golden flows (the same 1e-4 / 1e-5 bars
+    as the fp32 instruction path).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import pivlfn
+import pivlfn_oracle as orc
+from pivlfn import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+# cout, cin, kh, kw, B, H, W
+LAYERS = [(128, 128, 3, 3, 1, 128, 128),   # <2,2> twice over the channels
+          (64, 128, 3, 3, 2, 64, 96),
+          (64, 64, 3, 3, 1, 72, 100),      # ragged edges
+          (32, 64, 3, 3, 1, 64, 64),       # <2,1>
+          (32, 32, 3, 3, 1, 37, 45),       # ragged
+          (128, 49, 3, 3, 1, 64, 64),      # conv_M.0: 49 channels in 52 lanes, K padded to 64
+          (128, 130, 3, 3, 1, 64, 64),     # 130 channels: 8 full chunks + a chunk of 2 (+2 zero lanes)
+          (64, 32, 1, 1, 1, 128, 128),     # 1x1 (NetC_ext)
+          (128, 32, 1, 1, 1, 64, 64),      # 1x1 (moduleFeat)
+          (49, 32, 7, 1, 1, 96, 96),       # separable k x 1, cout 49 -> 52 lanes
+          (49, 49, 1, 7, 1, 96, 96),       # 1 x k with a 52-lane source
+          (25, 32, 5, 5, 1, 64, 64),       # 5 x 5 (conv_dist_R.0 of the Hui layout)
+          (9, 32, 3, 3, 1, 64, 64)]
+
+
+def _run(lib, h, fn, x, xs, co, B, H, W, kh, kw, dev, terms=6):
+    ys = -(-co // 4) * 4
+    y = torch.full((B, H, W, ys), float("nan"), device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    if fn == "split":
+        _lib.check(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), xs, y.data_ptr(), ys, B, H, W, 1, kh // 2, kw // 2, 1, terms, st), "split")
+    else:
+        _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), xs, y.data_ptr(), ys, None, 0, B, H, W, 1, kh // 2, kw // 2, 1, st), "fp32")
+    torch.cuda.synchronize()
+    return y.cpu()
+
+
+def _layer_errors(layer, dev, wscale=1.0, xscale=1.0, mixed=False, terms=6):
+    co, ci, kh, kw, B, H, W = layer
+    g = torch.Generator().manual_seed(co * 1000 + ci * 10 + kh + H)
+    w = (torch.randn(co, ci, kh, kw, generator=g) / (ci * kh * kw) ** 0.5 * wscale).contiguous()
+    b = (torch.randn(co, generator=g) * wscale * xscale).contiguous()
+    xs = -(-ci // 4) * 4
+    x = torch.randn(B, H, W, xs, generator=g) * xscale
+    if mixed:                                   # magnitudes spread over 12 binades inside one layer
+        w = (w * torch.exp2(torch.randint(-12, 1, w.shape, generator=g).float())).contiguous()
+        x = x * torch.exp2(torch.randint(-12, 1, x.shape, generator=g).float())
+    x[..., ci:] = 0.0
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
+    xd = x.to(dev)
+    got_s = _run(lib, h, "split", xd, xs, co, B, H, W, kh, kw, dev, terms)
+    got_f = _run(lib, h, "fp32", xd, xs, co, B, H, W, kh, kw, dev)
+    lib.pivlfn_conv_destroy(h)
+    want = F.leaky_relu(F.conv2d(x[..., :ci].permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=(kh // 2, kw // 2)), 0.1).permute(0, 2, 3, 1)
+    assert torch.isfinite(got_s).all()
+    ys = got_s.shape[-1]
+    if ys > co:
+        assert (got_s[..., co:] == 0).all()                     # padding lanes are exact zeros
+    scale = want.abs().max().item()
+    es = (got_s[..., :co].double() - want).abs()
+    ef = (got_f[..., :co].double() - want).abs()
+    return es.max().item() / scale, ef.max().item() / scale, es.mean().item() / scale, ef.mean().item() / scale
+
+
+@pytest.mark.parametrize("terms", [6, 3])
+@pytest.mark.parametrize("layer", LAYERS, ids=[f"{c[0]}x{c[1]}k{c[2]}x{c[3]}_{c[4]}x{c[5]}x{c[6]}" for c in LAYERS])
+def test_split_kernel_has_the_fp32_kernels_error(layer, terms, dev):
+    es, ef, ms, mf = _layer_errors(layer, dev, terms=terms)
+    print(f"{terms} terms, max-abs error / max|out| against float64: split {es:.2e}, fp32 instruction {ef:.2e}; mean {ms:.2e} vs {mf:.2e}")
+    assert es < 2e-5, es                                        # the fp32 kernel's own bar (tests/test_gpu_conv.py)
+    assert ms < 2.0 * mf + 1e-9, (ms, mf)                       # and on average no worse than twice the fp32 instruction's
+
+
+@pytest.mark.parametrize("terms", [6, 3])
+@pytest.mark.parametrize("wscale,xscale", [(1e-6, 1.0), (1e3, 1.0), (1.0, 1e-4), (1.0, 1e3), (1e-5, 1e3), (3e2, 3e-3)])
+def test_split_kernel_accuracy_is_scale_free(wscale, xscale, terms, dev):
+    es, ef, ms, mf = _layer_errors((64, 128, 3, 3, 1, 64, 96), dev, wscale, xscale, terms=terms)
+    print(f"{terms} terms, w x {wscale:g}, x x {xscale:g}: split {es:.2e} (mean {ms:.2e}), fp32 instruction {ef:.2e} (mean {mf:.2e})")
+    assert es < 2e-5 and ms < 2.0 * mf + 1e-9
+
+
+@pytest.mark.parametrize("terms", [6, 3])
+def test_split_kernel_mixed_magnitudes(terms, dev):
+    es, ef, ms, mf = _layer_errors((64, 128, 3, 3, 1, 64, 96), dev, mixed=True, terms=terms)
+    print(f"{terms} terms, 12 binades of magnitudes in one layer: split {es:.2e} (mean {ms:.2e}), fp32 instruction {ef:.2e} (mean {mf:.2e})")
+    assert es < 2e-5 and ms < 2.0 * mf + 1e-9
+
+
+def test_split_kernel_rejects_strided_layers(dev):
+    lib = _lib.load()
+    w, b = torch.randn(32, 32, 3, 3).contiguous(), torch.zeros(32)
+    h = ctypes.c_void_p()
+    _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), 32, 32, 3, 3, ctypes.byref(h)), "create")
+    x = torch.zeros(1, 64, 64, 32, device=dev)
+    y = torch.zeros(1, 32, 32, 32, device=dev)
+    rc = lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), 32, y.data_ptr(), 32, 1, 64, 64, 2, 1, 1, 1, 6, torch.cuda.current_stream(dev).cuda_stream)
+    lib.pivlfn_conv_destroy(h)
+    assert rc != 0 and b"stride" in lib.pivlfn_last_error()
+
+
+E2E_MAX, E2E_MEAN = 1e-4, 1e-5          # the fp32 end-to-end tolerance, relative to max(1, max|flow|)
+
+
+def _check(got, want, what):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(1.0, np.abs(want).max())
+    err = np.abs(got - want)
+    print(f"{what}: max-abs {err.max():.2e}, mean-abs {err.mean():.2e} px at flow scale {scale:.2f}")
+    assert err.max() <= E2E_MAX * scale, f"{what}: max-abs {err.max():.3e} at flow scale {scale:.2f}"
+    assert err.mean() <= E2E_MEAN * scale, f"{what}: mean-abs {err.mean():.3e}"
+
+
+def test_default_precision_is_the_three_term_split(dev):
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    assert net.precision == "fp32_split3"
+
+
+@pytest.mark.parametrize("mode", ["fp32_split3", "fp32_split"])
+@pytest.mark.parametrize("model,size", [("piv", (256, 256)), ("hui", (256, 320)), ("piv", (512, 384)), ("piv", (512, 512))])
+def test_split_modes_meet_the_fp32_tolerance_against_the_oracle(model, size, mode, dev):
+    """Level 1 (and level 2 of the 512 x 512 pair) run on the split kernel; the bars are those of the fp32 instruction path."""
+    H, W = size
+    a, b, _ = synth.particle_pair(H, W, 1234 + H)
+    x1, x2 = torch.from_numpy(synth.to_input(a))[None], torch.from_numpy(synth.to_input(b))[None]
+    net = pivlfn.Network(model=model, params=synth.generate_weights(model, 0)).to(dev).eval()
+    net.precision = "fp32"
+    f32 = net(x1.to(dev), x2.to(dev)).cpu().numpy()
+    net.precision = mode
+    assert net.precision == mode
+    got = net(x1.to(dev), x2.to(dev)).cpu().numpy()
+    assert not np.array_equal(got, f32)                         # the mode really ran (summation orders differ)
+    onet = orc.make_net(model, synth.generate_weights(model, 0), corr="c")
+    with torch.no_grad():
+        want = onet.forward(x1, x2).numpy()
+    _check(f32, want, f"{model} {H}x{W} fp32 instruction vs oracle")
+    _check(got, want, f"{model} {H}x{W} {mode} vs oracle")
+    net.precision = "fp32"
+    assert np.array_equal(net(x1.to(dev), x2.to(dev)).cpu().numpy(), f32)     # switching back restores the bits
+
+
+def test_small_grids_never_reach_the_split_kernel(gold, dev):
+    """Golden 96 x 160 case (flows produced by the reference itself): no level has 256 x 256 outputs, so every fp32 mode is the
+    fp32 instruction path, bit for bit -- and meets the bars against the reference's flows."""
+    g = gold["e2e_cases"]
+    tag = "piv_2x96x160"
+    i1 = torch.from_numpy(np.stack([synth.to_input(a) for a in g[f"{tag}_img1"]])).to(dev)
+    i2 = torch.from_numpy(np.stack([synth.to_input(a) for a in g[f"{tag}_img2"]])).to(dev)
+    net = pivlfn.Network(model="piv", params=synth.generate_weights("piv", 0)).to(dev).eval()
+    outs = {}
+    for mode in ("fp32", "fp32_split", "fp32_split3"):
+        net.precision = mode
+        outs[mode] = net(i1, i2).cpu().numpy()
+    assert np.array_equal(outs["fp32"], outs["fp32_split"]) and np.array_equal(outs["fp32"], outs["fp32_split3"])
+    _check(outs["fp32_split3"], g[f"{tag}_flow"], f"{tag} vs reference flows")
+
+
+@pytest.mark.parametrize("mode", ["fp32_split3", "fp32_split"])
+def test_split_mode_batch_consistency(mode, dev):
+    """A pair's flow is the same bits alone and inside a batch (the kernel choice is made per image, never from the batch)."""
+    a, b = synth.particle_batch(3, 256, 256, seed=5)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    net.precision = mode
+    full = net(i1, i2)
+    for k in range(3):
+        assert torch.equal(net(i1[k:k + 1], i2[k:k + 1])[0], full[k])

@@ -124,7 +124,7 @@ def _level_layers(L, n):
             (f"L{L} R.6 64->64", 64, 64, 3, 1, n, 1), (f"L{L} R.8 64->32", 32, 64, 3, 1, n, 1), (f"L{L} R.10 32->32", 32, 32, 3, 1, n, 1)]
 
 
-CONV_SHAPES = _level_layers(1, 1024) + _level_layers(2, 512) + [
+CONV_SHAPES = _level_layers(1, 1024) + _level_layers(2, 512) + _level_layers(3, 256) + [
     # name, cout, cin, k, stride, H(=W) at the 1024x1024 PIV forward, batch multiplier
     ("L3 conv 128->128", 128, 128, 3, 1, 256, 1),
     ("L4 conv 128->128", 128, 128, 3, 1, 128, 1), ("L5 conv 128->128", 128, 128, 3, 1, 64, 1), ("L6 conv 128->128", 128, 128, 3, 1, 32, 1),
@@ -165,15 +165,22 @@ def bench_conv(args):
         for v in variants:
             # variants >= 100000 select the fp16-multiplicand kernel: even = fp32 in / fp32 out, odd = fp16 in / fp16 out;
             # (v - 100000) >> 1 goes to the tuning knob (pivlfn_tune(1, .)): 100000/100001 shipped policy, 100128/100129 = knob 64
-            f16io = v >= 100000 and (v & 1) == 1
+            # variants >= 2000000: the split-operand fp32 kernel (conv_split.hip), stride-1 layers only; 2xxxxxx = six terms,
+            # 3xxxxxx = three terms; v % 1000000 goes to the knob
+            split = v >= 2000000
+            if split and s != 1:
+                continue
+            f16io = 100000 <= v < 2000000 and (v & 1) == 1
             y = torch.empty(B, no, mo, ys, device=dev, dtype=torch.float16 if f16io else torch.float32)
             outs[v] = y
             if f16io and xh is None and ci % 8 == 0:
                 xh = x.half()
 
             def fn(v=v, y=y, f16io=f16io):
-                lib.pivlfn_tune(1, (v - 100000) >> 1 if v >= 100000 else v)
-                if v >= 100000:
+                lib.pivlfn_tune(1, (v % 1000000) if split else ((v - 100000) >> 1 if v >= 100000 else v))
+                if split:
+                    _chk(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), ci, y.data_ptr(), ys, B, n, n, 1, kh // 2, kw // 2, 1, 3 if v >= 3000000 else 6, st), "conv")
+                elif v >= 100000:
                     if f16io and ci % 8 == 0:
                         _chk(lib.pivlfn_conv2d_nhwc_f16(h, xh.data_ptr(), ci, 1, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
                     else:
@@ -183,6 +190,8 @@ def bench_conv(args):
             tmin, tmed = time_it(fn, n=10 if flop > 2e10 else 30, rounds=4)
             print(f"{name:28s} B={B} variant {v}: min {tmin:9.1f} us  med {tmed:9.1f} us  {flop / tmin / 1e6:7.1f} TFLOP/s (staged K)", flush=True)
         for v in variants[1:]:
+            if v not in outs or variants[0] not in outs:
+                continue
             d = (outs[v].float() - outs[variants[0]].float()).abs().max().item()
             print(f"    variant {v} vs {variants[0]}: max abs diff {d:.3e}")
         lib.pivlfn_conv_destroy(h)
