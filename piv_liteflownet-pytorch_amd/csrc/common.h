@@ -153,7 +153,7 @@ struct ConvParamsX {
     int dbg;            // ablation mask for tools/bench_ops.py (0 in production): 1 no MFMAs, 2 no global loads, 4 no LDS commit
 };
 int launch_conv_x(const ConvParamsX &p, hipStream_t st);
-bool conv_split_supports(int KH, int KW, int S, int cout_pad);
+bool conv_split_supports(int KH, int KW, int S, int cout_pad, int terms);
 // 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device
 int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                      int k, hipStream_t st);

@@ -285,10 +285,13 @@ static int launch_x(const ConvParamsX &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
-// Which layers the kernel takes (net.hip asks before routing): stride 1, at most 7 taps per kernel row, 16-byte granular sources.
-bool conv_split_supports(int KH, int KW, int S, int cout_pad)
+// Which layers the kernel takes (net.hip asks before routing): stride 1 with at most 7 taps per kernel row, or 3 x 3 at stride 2
+// with three-term products (4-row tiles: the stride-2 patch of an 8-row tile does not fit twice per CU); 16-byte granular sources.
+bool conv_split_supports(int KH, int KW, int S, int cout_pad, int terms)
 {
-    if (S != 1 || KW > 7 || KH > 7 || cout_pad % 32 != 0) return false;
+    if (cout_pad % 32 != 0) return false;
+    if (S == 2) return terms == 3 && KH == 3 && KW == 3;
+    if (S != 1 || KW > 7 || KH > 7) return false;
     const int PH = 7 + KH, PW = 31 + KW;                 // 8-row tile
     const int bn = cout_pad % 64 == 0 ? 64 : 32;
     const size_t lds = ((size_t)PH * PW * 56 + (size_t)KW * 6 * bn * 8) * 2 + bn * 4;      // the six-term layout, the larger one
@@ -304,12 +307,15 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
     for (int i = 0; i < p.nseg; ++i)
         PIV_REQUIRE(p.seg[i].ptr && p.seg[i].cload % 4 == 0 && p.seg[i].stride % 4 == 0, "conv_split: source %d must be 16-byte granular", i);
     PIV_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.B > 0, "conv_split: empty output");
-    PIV_REQUIRE(conv_split_supports(p.KH, p.KW, p.S, p.cout_pad), "conv_split: unsupported geometry k=%dx%d s=%d", p.KH, p.KW, p.S);
     if (PIV_KNOB(1) & 65536) p.terms = 3;     // tools: three-term products whatever the caller asked for
+    PIV_REQUIRE(conv_split_supports(p.KH, p.KW, p.S, p.cout_pad, p.terms), "conv_split: unsupported geometry k=%dx%d stride %d with %d-term products", p.KH, p.KW, p.S, p.terms);
+    if (p.S == 2) return p.cout_pad % 64 == 0 ? launch_x<3, 1, 2, 5, 3, 2>(p, st) : launch_x<3, 1, 1, 5, 2, 2>(p, st);
     const bool wide = p.KW > 3;                       // 1 x k / k x k rows of 5 or 7 taps: the larger weight-row class
     const bool tall = (7 + p.KH) * (31 + p.KW) * 2 > 256 * 3;
     if (p.terms == 3) {
-        if (p.cout_pad % 128 == 0 && !wide && !tall && !(PIV_KNOB(1) & 131072)) return launch_x<3, 2, 4, 3, 6, 2>(p, st);
+        // 128-channel tiles unless that leaves fewer than four workgroups per CU (tile shapes never change a result's bits)
+        const long t128 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B * (p.cout_pad / 128);
+        if (p.cout_pad % 128 == 0 && !wide && !tall && t128 >= 1024 && !(PIV_KNOB(1) & 131072)) return launch_x<3, 2, 4, 3, 6, 2>(p, st);
         if (p.cout_pad % 64 == 0) {
             if (wide) return launch_x<3, 2, 2, 5, 7, 2>(p, st);
             return tall ? launch_x<3, 2, 2, 5, 3, 2>(p, st) : launch_x<3, 2, 2, 3, 3, 3>(p, st);

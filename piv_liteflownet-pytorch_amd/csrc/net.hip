@@ -162,7 +162,7 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         PIV_CHECK_HIP(hipMemcpy(d, ph.data(), ph.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         out->wpk_h = d;
     }
-    if (conv_split_supports(kh, kw, 1, cp)) {   // the split-operand packing of the same layer (fp32 on the fp16 matrix cores)
+    if (conv_split_supports(kh, kw, 1, cp, 6)) {   // the split-operand packing of the same layer (fp32 on the fp16 matrix cores)
         std::vector<int> cr, cl, co;
         for (auto &sg : segs) { cr.push_back(sg.creal); cl.push_back(sg.cload); co.push_back(sg.coff); }
         std::vector<unsigned short> px;
@@ -508,7 +508,8 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
     // cores with split fp32 operands (conv_split.hip); coarser grids have too few 8-row tiles for its two workgroups per CU and
     // stay on the fp32 instruction kernel (measured at 1024^2, 512^2 and 256^2: tools/split_threshold.py).  Per image: the
     // choice never depends on the batch.
-    if (t_precision >= 2 && !res && S == 1 && cw.wpk_x && (long)Ho * Wo >= (PIV_KNOB(11) ? PIV_KNOB(11) : 256 * 256)) {
+    if (t_precision >= 2 && !res && cw.wpk_x && conv_split_supports(cw.KH, cw.KW, S, cw.cout_pad, t_precision == 3 ? 3 : 6) &&
+        (long)Ho * Wo >= (PIV_KNOB(11) ? PIV_KNOB(11) : 256 * 256)) {
         ConvParamsX q;
         memset(&q, 0, sizeof(q));
         int i = 0;
@@ -574,7 +575,8 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
 {
     PIV_REQUIRE(c && x && y, "conv2d_split: null argument");
     PIV_REQUIRE(terms == 6 || terms == 3, "conv2d_split: terms=%d (6 or 3 partial products per product)", terms);
-    PIV_REQUIRE(c->cw.wpk_x && stride == 1, "conv2d_split: this layer's geometry (k=%dx%d, stride %d) is not covered by the split kernel", c->cw.KH, c->cw.KW, stride);
+    PIV_REQUIRE(c->cw.wpk_x && conv_split_supports(c->cw.KH, c->cw.KW, stride, c->cw.cout_pad, terms),
+                "conv2d_split: this layer's geometry (k=%dx%d, stride %d, %d-term products) is not covered by the split kernel", c->cw.KH, c->cw.KW, stride, terms);
     PIV_REQUIRE(x_stride % 4 == 0 && x_stride >= rup(c->cin, 4), "conv2d_split: x_stride=%d must be a multiple of 4 and >= %d", x_stride, rup(c->cin, 4));
     PIV_REQUIRE(y_stride % 4 == 0 && y_stride >= c->cw.cout, "conv2d_split: y_stride=%d must be a multiple of 4 and >= cout=%d", y_stride, c->cw.cout);
     PIV_REQUIRE(pad_y >= 0 && pad_x >= 0 && H + 2 * pad_y >= c->cw.KH && W + 2 * pad_x >= c->cw.KW, "conv2d_split: bad geometry");
@@ -585,9 +587,9 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     q.wpk = c->cw.wpk_x; q.bias = c->cw.bias; q.out = y; q.out_stride = y_stride;
     q.cout_store = std::min(rup(c->cw.cout, 4), y_stride);
     q.cout_pad = c->cw.cout_pad; q.out_scale = c->cw.scale_x; q.terms = terms;
-    q.B = B; q.H = H; q.W = W; q.KH = c->cw.KH; q.KW = c->cw.KW; q.S = 1; q.padY = pad_y; q.padX = pad_x;
-    q.Ho = H + 2 * pad_y - c->cw.KH + 1;
-    q.Wo = W + 2 * pad_x - c->cw.KW + 1;
+    q.B = B; q.H = H; q.W = W; q.KH = c->cw.KH; q.KW = c->cw.KW; q.S = stride; q.padY = pad_y; q.padX = pad_x;
+    q.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
+    q.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
     q.nchunk = c->cw.nchunk_x; q.lrelu = leaky;
     return launch_conv_x(q, st);
 }

@@ -105,6 +105,32 @@ def test_split_kernel_mixed_magnitudes(terms, dev):
     assert es < 2e-5 and ms < 2.0 * mf + 1e-9
 
 
+@pytest.mark.parametrize("layer", [(32, 32, 1, 128, 160), (64, 32, 2, 96, 128), (64, 64, 1, 70, 90)], ids=["32x32", "64x32", "64x64ragged"])
+def test_three_term_kernel_stride_2(layer, dev):
+    """3 x 3 stride-2 layers (NetC.conv2.0 / conv3.0) on the three-term kernel's 4-row tiles, against float64."""
+    co, ci, B, H, W = layer
+    g = torch.Generator().manual_seed(co + ci + H)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).contiguous()
+    b = torch.randn(co, generator=g).contiguous()
+    x = torch.randn(B, H, W, ci, generator=g)
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(h)), "create")
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    xd = x.to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ys, yf = torch.full((B, Ho, Wo, co), float("nan"), device=dev), torch.full((B, Ho, Wo, co), float("nan"), device=dev)
+    _lib.check(lib.pivlfn_conv2d_nhwc_split(h, xd.data_ptr(), ci, ys.data_ptr(), co, B, H, W, 2, 1, 1, 1, 3, st), "split s2")
+    _lib.check(lib.pivlfn_conv2d_nhwc(h, xd.data_ptr(), ci, yf.data_ptr(), co, None, 0, B, H, W, 2, 1, 1, 1, st), "fp32 s2")
+    torch.cuda.synchronize()
+    lib.pivlfn_conv_destroy(h)
+    want = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=2, padding=1), 0.1).permute(0, 2, 3, 1)
+    scale = want.abs().max().item()
+    es, ef = (ys.cpu().double() - want).abs(), (yf.cpu().double() - want).abs()
+    print(f"stride 2: split max {es.max().item() / scale:.2e} mean {es.mean().item() / scale:.2e}; fp32 instruction max {ef.max().item() / scale:.2e} mean {ef.mean().item() / scale:.2e}")
+    assert es.max().item() / scale < 2e-5 and es.mean().item() < 2.0 * ef.mean().item() + 1e-9 * scale
+
+
 def test_split_kernel_rejects_strided_layers(dev):
     lib = _lib.load()
     w, b = torch.randn(32, 32, 3, 3).contiguous(), torch.zeros(32)

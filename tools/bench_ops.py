@@ -168,7 +168,7 @@ def bench_conv(args):
             # variants >= 2000000: the split-operand fp32 kernel (conv_split.hip), stride-1 layers only; 2xxxxxx = six terms,
             # 3xxxxxx = three terms; v % 1000000 goes to the knob
             split = v >= 2000000
-            if split and s != 1:
+            if split and not (s == 1 or (s == 2 and v >= 3000000 and kh == 3 and kw == 3)):
                 continue
             f16io = 100000 <= v < 2000000 and (v & 1) == 1
             y = torch.empty(B, no, mo, ys, device=dev, dtype=torch.float16 if f16io else torch.float32)
@@ -179,7 +179,7 @@ def bench_conv(args):
             def fn(v=v, y=y, f16io=f16io):
                 lib.pivlfn_tune(1, (v % 1000000) if split else ((v - 100000) >> 1 if v >= 100000 else v))
                 if split:
-                    _chk(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), ci, y.data_ptr(), ys, B, n, n, 1, kh // 2, kw // 2, 1, 3 if v >= 3000000 else 6, st), "conv")
+                    _chk(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), ci, y.data_ptr(), ys, B, n, n, s, kh // 2, kw // 2, 1, 3 if v >= 3000000 else 6, st), "conv")
                 elif v >= 100000:
                     if f16io and ci % 8 == 0:
                         _chk(lib.pivlfn_conv2d_nhwc_f16(h, xh.data_ptr(), ci, 1, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")

@@ -11,10 +11,14 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-template <int NR, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 1) void k(const _Float16 *src, float *dst, unsigned long long *clk, int iters)
+// BAR: workgroup barriers per 3 iterations ("kernel row" of 3 taps): 0 none, 1, 2 (the shipped kernel's phase structure);
+// WGS: workgroups per CU.  PKMUL: derive one operand per 6 MFMAs with v_pk_mul_f16 as conv_split.hip does.
+template <int NR, int WAVES, int BAR = 0, int WGS = 1, bool PKMUL = false>
+__global__ __launch_bounds__(WAVES * 64, WGS) void k(const _Float16 *src, float *dst, unsigned long long *clk, int iters)
 {
     __shared__ __attribute__((aligned(16))) _Float16 lds[32768];
+    const h8 k11 = {(_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f,
+                    (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f};
     for (int i = threadIdx.x; i < 32768; i += WAVES * 64) lds[i] = src[(blockIdx.x * 32768 + i) & 0xFFFFF];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -30,12 +34,21 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k(const _Float16 *src, float *d
 #pragma unroll
         for (int j = 0; j < 12; ++j) f[j] = *reinterpret_cast<const h8 *>(lds + ((base + 1352 * (j % NR)) & 32760));
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n) {
+            if (PKMUL) f[6 + n * 3 + 2] = f[6 + n * 3] * k11;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int q = 0; q < 6; ++q)
                     acc[m * 2 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[6 + n * 3 + q % 3], f[m * 3 + q / 2], acc[m * 2 + n], 0, 0, 0);
+        }
+        if (BAR && it % 3 == 2) {
+            __syncthreads();
+            if (BAR == 2) {
+                lds[(threadIdx.x * 8 + it) & 32767] = (_Float16)acc[0][0];      // a token LDS write between the two barriers
+                __syncthreads();
+            }
+        }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
@@ -47,16 +60,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k(const _Float16 *src, float *d
     if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
 
-template <int NR, int WAVES>
+template <int NR, int WAVES, int BAR = 0, int WGS = 1, bool PKMUL = false>
 static void run(const char *tag, const _Float16 *src, float *dst, unsigned long long *clk, int nb, int iters)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<NR, WAVES>), dim3(nb), dim3(WAVES * 64), 0, 0, src, dst, clk, iters);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<NR, WAVES, BAR, WGS, PKMUL>), dim3(nb), dim3(WAVES * 64), 0, 0, src, dst, clk, iters);
     hipEventRecord(e0);
     const int reps = 10;
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k<NR, WAVES>), dim3(nb), dim3(WAVES * 64), 0, 0, src, dst, clk, iters);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k<NR, WAVES, BAR, WGS, PKMUL>), dim3(nb), dim3(WAVES * 64), 0, 0, src, dst, clk, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -83,8 +96,8 @@ int main()
     unsigned long long *clk;
     hipMalloc(&src, h.size() * 2);
     hipMalloc(&zero, h.size() * 2);
-    hipMalloc(&dst, nb * 512 * 4);
-    hipMalloc(&clk, nb * 8);
+    hipMalloc(&dst, 2 * nb * 512 * 4);
+    hipMalloc(&clk, 2 * nb * 8);
     hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(zero, z.data(), z.size() * 2, hipMemcpyHostToDevice);
     for (int round = 0; round < 2; ++round) {
@@ -94,5 +107,11 @@ int main()
         run<12, 4>("4 waves, 12 reads, random operands", src, dst, clk, nb, iters);
         run<12, 4>("4 waves, 12 reads, zero operands", zero, dst, clk, nb, iters);
     }
+    // the shipped kernel's skeleton: two 4-wave workgroups per CU (512 workgroups), barriers per kernel row
+    run<12, 4, 0, 2>("2x4 waves, no barrier", src, dst, clk, 2 * nb, iters);
+    run<12, 4, 1, 2>("2x4 waves, 1 barrier / 3 taps", src, dst, clk, 2 * nb, iters);
+    run<12, 4, 2, 2>("2x4 waves, 2 barriers / 3 taps", src, dst, clk, 2 * nb, iters);
+    run<12, 4, 2, 2, true>("2x4 waves, 2 barriers, pk_mul", src, dst, clk, 2 * nb, iters);
+    run<12, 8, 1, 1>("1x8 waves, 1 barrier / 3 taps", src, dst, clk, nb, iters);
     return 0;
 }
