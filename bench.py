@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--model", default="piv", choices=["piv", "hui"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-arithmetic", action="store_true", help="skip the side-by-side timing of the three fp32 conv arithmetics")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed warm runs of the CPU baseline (median reported)")
     ap.add_argument("--precision", default="fp32_split3", choices=["fp32_split3", "fp32_split", "fp32", "fp16"],
                     help="how the large convolutions multiply: fp32_split3 (the library's default: fp32 operands as two fp16 pieces, "
@@ -343,7 +344,7 @@ def main():
                                       "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2]}
         if world == 1 and args.model == "piv" and S == 1024:
             out["roofline_batch8"] = l3_throughput_regime(dev)
-        if world == 1 and fp32_grade:
+        if world == 1 and fp32_grade and not args.no_arithmetic:
             out["arithmetic"] = arithmetic_modes(net, i1, i2, min(args.steps, 10), dev)
         if not args.no_cpu_baseline and world == 1:
             ref, cb = cpu_baseline(args.model, S, wts, i1c, i2c, runs=args.cpu_runs)

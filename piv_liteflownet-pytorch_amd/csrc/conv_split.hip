@@ -318,6 +318,10 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
         if (p.cout_pad % 128 == 0 && !wide && !tall && t128 >= 1024 && !(PIV_KNOB(1) & 131072)) return launch_x<3, 2, 4, 3, 6, 2>(p, st);
         if (p.cout_pad % 64 == 0) {
             if (wide) return launch_x<3, 2, 2, 5, 7, 2>(p, st);
+            // 3 x 3 with 64 channels: 16-row tiles (12 LDS operand reads per 24 MFMAs instead of 8 per 12) while four workgroups per
+            // CU remain; 128->64 at 1024^2: 478 -> 450 us.  (32-channel layers lose with 16 rows: 157 -> 162 us; 1 x 1: 183 -> 200.)
+            const long t16 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 16) * p.B * (p.cout_pad / 64);
+            if (p.KH == 3 && p.KW == 3 && t16 >= 1024 && !(PIV_KNOB(1) & 524288)) return launch_x<3, 4, 2, 5, 3, 2>(p, st);
             return tall ? launch_x<3, 2, 2, 5, 3, 2>(p, st) : launch_x<3, 2, 2, 3, 3, 3>(p, st);
         }
         if (wide) return launch_x<3, 2, 1, 5, 4, 2>(p, st);

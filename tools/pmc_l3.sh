@@ -6,7 +6,7 @@ set -e
 OUT=$PWD/gpurun_out/pmc_l3
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0 --no-arithmetic"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $grp | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/$tag" -- $CMD > "$OUT/$tag.log" 2>&1

@@ -63,5 +63,5 @@ print(json.dumps({
     "algorithmic_bytes_per_launch": alg,
     "TCC_HIT_sum": mean(res.get("TCC_HIT_sum", {})), "TCC_MISS_sum": mean(res.get("TCC_MISS_sum", {})),
     "kernel_source_sha256_16": h.hexdigest()[:16],
-    "passes": "three separate rocprofv3 --pmc runs of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0` (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum), tools/pmc_l3.sh",
+    "passes": "three separate rocprofv3 --pmc runs of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0 --no-arithmetic` (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum), tools/pmc_l3.sh",
 }, indent=1))
