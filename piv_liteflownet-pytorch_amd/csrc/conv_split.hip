@@ -285,6 +285,266 @@ static int launch_x(const ConvParamsX &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
+// ---- 16-row tile, one workgroup per CU, everything double-buffered (three-term products, 3 x 3 stride 1) ---------------------
+// conv_split_kernel's two workgroups per CU each alternate staging -> barrier -> MFMAs -> barrier: the matrix pipe idles whenever
+// both are outside their MFMA block.  Here one workgroup of four waves owns the CU and a wave never leaves its MFMA stream:
+//   * a wave computes 4 rows x 32 px x 32 NT channels: 16 LDS operand reads per 12 NT MFMAs and tap (NT = 4: 0.33 per MFMA
+//     instead of 0.5), 64 NT accumulator registers out of the 512 a wave has at this occupancy;
+//   * patch and weight rows are double-buffered in LDS: what a phase (chunk c, kernel row ky) stages -- its share of chunk c+1's
+//     patch, split into fp16 pieces, and weight row ph+1 -- is only read after the next barrier; one barrier per phase;
+//   * the operand fragments of tap kx+1 are read from LDS before the MFMAs of tap kx are issued (two register sets);
+//   * the phase body is straight-line code (no branches: out-of-image pixels and channel tails are buffer loads with an
+//     out-of-range offset, which return zero; past-the-end stages are clamped to the last chunk / row and land in a buffer nobody
+//     reads), so that the compiler can place the staging VALU / LDS / memory instructions between the MFMAs.
+constexpr unsigned XOOB = 0x80000000u;
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv_split_big_kernel(const ConvParamsX p)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 xsmem[];
+    constexpr int XPITCH = 40;                   // two pieces x 16 channels + 8 halfs of padding (80 bytes)
+    constexpr int BN = NT * 32;
+    constexpr int MT = 4, TH = 16, PH = 18, PW = 34, NPIX = PH * PW;       // 612 staged pixels
+    constexpr int PM = 5;                        // patch items per thread: pixel (tid >> 1) + 128 i, channel half tid & 1
+    constexpr int WROW = 3 * 2 * 2 * BN * 8;     // halfs per staged weight row [kx][piece][k-half][BN][8]
+    constexpr int WM = 3 * 2 * 2 * BN / 256;     // 16-byte weight units per thread and row (6 / 3)
+    constexpr int PBUF = (NPIX + 1) * XPITCH;    // one patch buffer: the staged pixels + a spare record (target of items that do not exist)
+    _Float16 *patch0 = xsmem;
+    _Float16 *wts0 = xsmem + 2 * PBUF;
+    float *lbias = reinterpret_cast<float *>(wts0 + 2 * WROW);
+
+    const int tiles_x = (p.Wo + 31) >> 5;
+    const int tiles_y = (p.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int n0 = blockIdx.y * BN;
+    const int x0 = tx * 32, y0 = ty * TH;
+    const int ix0 = x0 - p.padX, iy0 = y0 - p.padY;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 31, hh = lane >> 5;
+    const int sub = tid & 1;
+
+    if (tid < BN) lbias[tid] = p.bias[n0 + tid];       // visible after the first barrier
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = ((wave * MT + m) * PW + row) * XPITCH + hh * 8;
+    const int bbase = (hh * BN + row) * 8;
+
+    // staged pixel -> byte offset inside its image's source record (times the pixel stride later), XOOB = outside / no item
+    unsigned ppix[PM];
+    int pdst[PM];            // LDS half offset of the item's record (the spare record for items that do not exist)
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+        const int pix = (tid >> 1) + 128 * i;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool in = pix < NPIX && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        ppix[i] = in ? (unsigned)(iy * p.W + ix) : XOOB;
+        pdst[i] = (pix < NPIX ? pix : NPIX) * XPITCH + 4 * sub;
+    }
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + n0;
+    const size_t wrow = (size_t)3 * 6 * p.cout_pad;      // 16-byte units per (chunk, ky) in the packed weights (3 pieces)
+    int wsrc_off[WM];       // unit offset of this thread's weight items inside a packed row (pieces 0 and 1 of the 3 stored)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / BN;                           // staged row (kx * 2 + piece) * 2 + k-half
+        wsrc_off[i] = ((r >> 2) * 6 + (r & 3)) * p.cout_pad + (idx % BN);
+    }
+
+    f32x4 pr[2 * PM], wr[WM];
+    // the chunk whose patch is loaded next
+    int seg = 0, c0 = 0, lchunk = 0;
+    int scl = p.seg[0].cload, sst4 = p.seg[0].stride * 4;
+    const size_t img_px = (size_t)p.H * p.W;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[0].ptr + (size_t)b * img_px * p.seg[0].stride), 0,
+                                                                    (unsigned)(((img_px - 1) * p.seg[0].stride + p.seg[0].cload) * 4), 0x00020000);
+#define XB_ADVANCE()                                                                              \
+    do {                                                                                          \
+        if (lchunk + 1 < p.nchunk) {                                                              \
+            ++lchunk;                                                                             \
+            c0 += 16;                                                                             \
+            if (c0 >= scl) {                                                                      \
+                ++seg;                                                                            \
+                c0 = 0;                                                                           \
+                scl = p.seg[seg].cload; sst4 = p.seg[seg].stride * 4;                             \
+                rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + (size_t)b * img_px * p.seg[seg].stride), 0, \
+                                                       (unsigned)(((img_px - 1) * p.seg[seg].stride + p.seg[seg].cload) * 4), 0x00020000); \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+#define XB_LOAD_ITEM(I)                                                                           \
+    do {                                                                                          \
+        const unsigned base_ = ppix[I] == XOOB ? XOOB : ppix[I] * (unsigned)sst4 + (unsigned)(c0 + 4 * sub) * 4u; \
+        const unsigned o0_ = (c0 + 4 * sub < scl) ? base_ : XOOB;                                 \
+        const unsigned o1_ = (c0 + 8 + 4 * sub < scl && base_ != XOOB) ? base_ + 32u : XOOB;      \
+        pr[2 * (I)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0_, 0, 0));      \
+        pr[2 * (I) + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o1_, 0, 0));  \
+    } while (0)
+#define XB_COMMIT_ITEM(I, DST)                                                                    \
+    do {                                                                                          \
+        _Float16 *d_ = (DST) + pdst[I];                                                           \
+        h4 ph_[2], pm_[2];                                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                        \
+            const f32x4 v_ = pr[2 * (I) + e_];                                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                    \
+                const _Float16 a_ = (_Float16)v_[j_];                                             \
+                ph_[e_][j_] = a_;                                                                 \
+                pm_[e_][j_] = (_Float16)((v_[j_] - (float)a_) * 2048.f);                          \
+            }                                                                                     \
+        }                                                                                         \
+        *reinterpret_cast<h4 *>(d_) = ph_[0];                                                     \
+        *reinterpret_cast<h4 *>(d_ + 8) = ph_[1];                                                 \
+        *reinterpret_cast<h4 *>(d_ + 16) = pm_[0];                                                \
+        *reinterpret_cast<h4 *>(d_ + 24) = pm_[1];                                                \
+    } while (0)
+#define XB_LOAD_W(ROWIDX)                                                                         \
+    do {                                                                                          \
+        const f32x4 *wc_ = wsrc + (size_t)(ROWIDX)*wrow;                                          \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) wr[i] = wc_[wsrc_off[i]];                  \
+    } while (0)
+#define XB_COMMIT_W(DST)                                                                          \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) reinterpret_cast<f32x4 *>(DST)[tid + 256 * i] = wr[i]; \
+    } while (0)
+#define XB_FRAGS(KY, KX, FA, FW)                                                                  \
+    do {                                                                                          \
+        const int toff_ = ((KY)*PW + (KX)) * XPITCH;                                              \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                          \
+            FA[m][0] = *reinterpret_cast<const h8 *>(patch + abase[m] + toff_);                   \
+            FA[m][1] = *reinterpret_cast<const h8 *>(patch + abase[m] + toff_ + 16);              \
+        }                                                                                         \
+        const _Float16 *wk_ = wts + (KX)*4 * BN * 8 + bbase;                                      \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                          \
+            FW[n][0] = *reinterpret_cast<const h8 *>(wk_ + n * 256);                              \
+            FW[n][1] = *reinterpret_cast<const h8 *>(wk_ + 2 * BN * 8 + n * 256);                 \
+        }                                                                                         \
+    } while (0)
+#define XB_TAP(FA, FW)                                                                            \
+    do {                                                                                          \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                          \
+            const h8 w0m_ = FW[n][0] * k11;                                                       \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                      \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0m_, FA[m][1], acc[m][n], 0, 0, 0);     \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[n][1], FA[m][0], acc[m][n], 0, 0, 0); \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[n][0], FA[m][0], acc[m][n], 0, 0, 0); \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+// phase KY of the current chunk: items I0 (and I1, -1 = none) of the next chunk's patch are staged in it
+#define XB_PHASE(KY, I0, I1)                                                                      \
+    do {                                                                                          \
+        const _Float16 *wts = wts0 + (ph & 1) * WROW;                                             \
+        _Float16 *wts_next = wts0 + ((ph + 1) & 1) * WROW;                                        \
+        h8 fa0[MT][2], fw0[NT][2], fa1[MT][2], fw1[NT][2];                                        \
+        XB_FRAGS(KY, 0, fa0, fw0);                                                                \
+        XB_FRAGS(KY, 1, fa1, fw1);                                                                \
+        XB_TAP(fa0, fw0);                                                                         \
+        XB_COMMIT_W(wts_next);                                                                    \
+        XB_COMMIT_ITEM(I0, patch_next);                                                           \
+        if ((I1) >= 0) XB_COMMIT_ITEM((I1) >= 0 ? (I1) : 0, patch_next);                          \
+        XB_FRAGS(KY, 2, fa0, fw0);                                                                \
+        XB_TAP(fa1, fw1);                                                                         \
+        XB_LOAD_W(ph + 2 < nph ? ph + 2 : nph - 1);                                               \
+        XB_LOAD_ITEM(I0);                                                                         \
+        if ((I1) >= 0) XB_LOAD_ITEM((I1) >= 0 ? (I1) : 0);                                        \
+        XB_TAP(fa0, fw0);                                                                         \
+        __syncthreads();                                                                          \
+        ++ph;                                                                                     \
+    } while (0)
+
+    const h8 k11 = {(_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f,
+                    (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f};
+    const int nph = p.nchunk * 3;
+    // prologue: chunk 0 and weight row 0 into LDS, chunk 1 and row 1 into registers
+#pragma unroll
+    for (int i = 0; i < PM; ++i) XB_LOAD_ITEM(i);
+    XB_LOAD_W(0);
+#pragma unroll
+    for (int i = 0; i < PM; ++i) XB_COMMIT_ITEM(i, patch0);
+    XB_COMMIT_W(wts0);
+    XB_ADVANCE();
+#pragma unroll
+    for (int i = 0; i < PM; ++i) XB_LOAD_ITEM(i);
+    XB_LOAD_W(nph > 1 ? 1 : 0);
+    __syncthreads();
+
+    int ph = 0;
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        const _Float16 *patch = patch0 + (chunk & 1) * PBUF;
+        _Float16 *patch_next = patch0 + ((chunk + 1) & 1) * PBUF;
+        XB_ADVANCE();            // the registers this chunk's phases free are refilled with chunk + 2 (clamped to the last chunk)
+        XB_PHASE(0, 0, 1);
+        XB_PHASE(1, 2, 3);
+        XB_PHASE(2, 4, -1);
+    }
+#undef XB_ADVANCE
+#undef XB_LOAD_ITEM
+#undef XB_COMMIT_ITEM
+#undef XB_LOAD_W
+#undef XB_COMMIT_W
+#undef XB_FRAGS
+#undef XB_TAP
+#undef XB_PHASE
+
+    {
+        const int ox = x0 + row;
+        const bool interior = x0 + 32 <= p.Wo && y0 + TH <= p.Ho && n0 + BN <= p.cout_store;
+        const float sc = p.out_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + wave * MT + m;
+            const bool pix_ok = interior || (oy < p.Ho && ox < p.Wo);
+            const size_t pix = (size_t)(b * p.Ho + (oy < p.Ho ? oy : 0)) * p.Wo + (ox < p.Wo ? ox : 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n0 + n * 32 + 8 * g + 4 * hh;
+                    if (!pix_ok || (!interior && ch >= p.cout_store)) continue;
+                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(lbias + (ch - n0));
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * g + j] * sc + bq[j];
+                    if (p.lrelu) {
+                        v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                    }
+                    *reinterpret_cast<f32x4 *>(p.out + pix * p.out_stride + ch) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static int launch_xbig(const ConvParamsX &p, hipStream_t st)
+{
+    constexpr int BN = NT * 32;
+    const size_t lds = ((size_t)2 * 613 * 40 + (size_t)2 * 3 * 4 * BN * 8) * sizeof(_Float16) + BN * sizeof(float);
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_split_big_kernel<NT>), 160 * 1024)) return rc;
+    const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, 16) * p.B;
+    dim3 grid(tiles, p.cout_pad / BN);
+    hipLaunchKernelGGL((conv_split_big_kernel<NT>), grid, dim3(256), lds, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
 // Which layers the kernel takes (net.hip asks before routing): stride 1 with at most 7 taps per kernel row, or 3 x 3 at stride 2
 // with three-term products (4-row tiles: the stride-2 patch of an 8-row tile does not fit twice per CU); 16-byte granular sources.
 bool conv_split_supports(int KH, int KW, int S, int cout_pad, int terms)
@@ -313,9 +573,19 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
     const bool wide = p.KW > 3;                       // 1 x k / k x k rows of 5 or 7 taps: the larger weight-row class
     const bool tall = (7 + p.KH) * (31 + p.KW) * 2 > 256 * 3;
     if (p.terms == 3) {
+        // 128 channels, 3 x 3, at least two 16-row tiles per CU and six K chunks: the one-workgroup-per-CU kernel (bit-identical
+        // results; 128->128 at 1024^2: 841 -> 769 us, at 512^2: 221 -> 196; fewer tiles or chunks: its prologue does not pay)
+        const long t16 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 16) * p.B;
+        const bool fits31 = (size_t)p.H * p.W * 4 * 160 < ((size_t)1 << 31);      // 32-bit buffer offsets inside one image
+        if (p.cout_pad % 128 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 128) >= 512 && p.nchunk >= 6 && fits31 &&
+            !(PIV_KNOB(1) & 262144))
+            return launch_xbig<4>(p, st);
+        if (p.cout_pad % 64 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 64) >= 512 && p.nchunk >= 6 && fits31 &&
+            !(PIV_KNOB(1) & 131072))
+            return launch_xbig<2>(p, st);       // 128->64 at 1024^2: 476 -> 445 us
         // 128-channel tiles unless that leaves fewer than four workgroups per CU (tile shapes never change a result's bits)
         const long t128 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B * (p.cout_pad / 128);
-        if (p.cout_pad % 128 == 0 && !wide && !tall && t128 >= 1024 && !(PIV_KNOB(1) & 131072)) return launch_x<3, 2, 4, 3, 6, 2>(p, st);
+        if (p.cout_pad % 128 == 0 && !wide && !tall && t128 >= 1024) return launch_x<3, 2, 4, 3, 6, 2>(p, st);
         if (p.cout_pad % 64 == 0) {
             if (wide) return launch_x<3, 2, 2, 5, 7, 2>(p, st);
             // 3 x 3 with 64 channels: 16-row tiles (12 LDS operand reads per 24 MFMAs instead of 8 per 12) while four workgroups per
