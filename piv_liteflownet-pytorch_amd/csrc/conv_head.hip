@@ -12,6 +12,14 @@
 namespace pivlfn {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// (a0, a1) += x * (w0, w1): one v_pk_fma_f32 -- both outputs of a pixel per instruction, the weight pair from one 64-bit scalar
+// operand.  Per output the chain of fused multiply-adds is the one of the scalar form, so the bits do not change.
+__device__ __forceinline__ f32x2 fma2(float x, const float *w2, f32x2 a)
+{
+    return __builtin_elementwise_fma(f32x2{x, x}, *reinterpret_cast<const f32x2 *>(w2), a);
+}
 
 // WLDS: weights staged in LDS and read as broadcast ds_reads instead of through the scalar cache.  On a grid of a few
 // workgroups (the coarse levels) the K*K*8 dependent s_load round trips are the whole kernel (22 us for 32x32 pixels); with many
@@ -47,10 +55,10 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float *__restrict_
 
     const int lx = tid & 15, ly = tid >> 4;
     const char *sb = reinterpret_cast<const char *>(smem);
-    float a0 = 0.f, a1 = 0.f;
+    f32x2 a = {0.f, 0.f};
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
-        const float *wr = (WLDS ? wl : w) + ky * K * 64;      // [kx][quad][out][4]
+        const float *wr = (WLDS ? wl : w) + ky * K * 64;      // [kx][quad][4][out]
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
             const int c = lx + kx;
@@ -59,15 +67,14 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const float *__restrict_
             for (int q = 0; q < 8; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + (base ^ (unsigned)(16 * q)));
                 const float *wq = wr + (kx * 8 + q) * 8;
-                a0 = fmaf(v[0], wq[0], a0); a0 = fmaf(v[1], wq[1], a0); a0 = fmaf(v[2], wq[2], a0); a0 = fmaf(v[3], wq[3], a0);
-                a1 = fmaf(v[0], wq[4], a1); a1 = fmaf(v[1], wq[5], a1); a1 = fmaf(v[2], wq[6], a1); a1 = fmaf(v[3], wq[7], a1);
+                a = fma2(v[0], wq, a); a = fma2(v[1], wq + 2, a); a = fma2(v[2], wq + 4, a); a = fma2(v[3], wq + 6, a);
             }
         }
     }
     const int oy = ty0 + ly, ox = tx0 + lx;
     if (oy < H && ox < W) {
         const size_t pix = ((size_t)b * H + oy) * W + ox;
-        f32x4 o = {a0 + b0, a1 + b1, 0.f, 0.f};
+        f32x4 o = {a[0] + b0, a[1] + b1, 0.f, 0.f};
         if (res4) {
             const float2 r = *reinterpret_cast<const float2 *>(res4 + pix * 4);
             o[0] += r.x;
@@ -103,9 +110,9 @@ __global__ __launch_bounds__(256, 3) void conv_head4_kernel(const float *__restr
     const int lx = (wave & 1) * 16 + (lane & 15);          // column of this lane inside the tile
     const int ly0 = (wave >> 1) * 16 + (lane >> 4) * 4;    // first of its four rows
 
-    float a[4][2];
+    f32x2 a[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i][0] = a[i][1] = 0.f;
+    for (int i = 0; i < 4; ++i) a[i] = f32x2{0.f, 0.f};
 
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void conv_head4_kernel(const float *__restr
             const int sw = (c >> 3) & 1;
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-                const float *wq = w + (kx * 8 + pass * 2 + qq) * 8;          // + ky * K * 64: [tap][quad][out][4]
+                const float *wq = w + (kx * 8 + pass * 2 + qq) * 8;          // + ky * K * 64: [tap][quad][4][out]
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + ((ly0 + r) * PW + c) * 8 + 4 * (qq ^ sw));
@@ -134,10 +141,8 @@ __global__ __launch_bounds__(256, 3) void conv_head4_kernel(const float *__restr
                         const int ky = r - i;
                         if (ky >= 0 && ky < K) {
                             const float *wk = wq + ky * K * 64;
-                            a[i][0] = fmaf(v[0], wk[0], a[i][0]); a[i][0] = fmaf(v[1], wk[1], a[i][0]);
-                            a[i][0] = fmaf(v[2], wk[2], a[i][0]); a[i][0] = fmaf(v[3], wk[3], a[i][0]);
-                            a[i][1] = fmaf(v[0], wk[4], a[i][1]); a[i][1] = fmaf(v[1], wk[5], a[i][1]);
-                            a[i][1] = fmaf(v[2], wk[6], a[i][1]); a[i][1] = fmaf(v[3], wk[7], a[i][1]);
+                            a[i] = fma2(v[0], wk, a[i]); a[i] = fma2(v[1], wk + 2, a[i]);
+                            a[i] = fma2(v[2], wk + 4, a[i]); a[i] = fma2(v[3], wk + 6, a[i]);
                         }
                     }
                 }
@@ -190,7 +195,7 @@ static int launch_head_t(const float *x, const float *w, float b0, float b1, con
     return PIVLFN_OK;
 }
 
-// w: device, [k*k][8][2][4] = (tap, channel quad, output, channel-in-quad)
+// w: device, [k*k][8][4][2] = (tap, channel quad, channel-in-quad, output)
 int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                      int k, hipStream_t st)
 {

@@ -37,7 +37,7 @@ struct ConvW {
 struct LevelW {
     float *upconv = nullptr, *upcorr = nullptr;    // depthwise k4 weights [16 taps][C4]
     ConvW M[6], S[6], R[6], feat, dist0, dist1;   // M/S: nstack hidden 3x3 layers, then the k x k head at index nstack
-    float *headM = nullptr, *headS = nullptr;      // VALU flow-head weights [k*k][8][2][4]
+    float *headM = nullptr, *headS = nullptr;      // VALU flow-head weights [k*k][8][4][2]
     float hbM[2] = {0.f, 0.f}, hbS[2] = {0.f, 0.f};
     float *wx = nullptr, *wy = nullptr;
     float bx = 0.f, by = 0.f;
@@ -186,7 +186,8 @@ static int pack_dw(pivlfn_net *net, const TMap &m, const std::string &name, int 
     return upload(net, h, dev);
 }
 
-// Flow-head weights for conv_head.hip: OIHW [2,32,k,k] -> [tap][channel quad][output][4]
+// Flow-head weights for conv_head.hip: OIHW [2,32,k,k] -> [tap][channel quad][4][output] (the two outputs of a channel adjacent:
+// one 64-bit scalar operand of a packed fp32 fma)
 static int pack_head(pivlfn_net *net, const TMap &m, const std::string &name, int k, float **dev, float bias[2])
 {
     const pivlfn_tensor *w = find(m, name + ".weight", 2, 32, k, k, 4);
@@ -197,7 +198,7 @@ static int pack_head(pivlfn_net *net, const TMap &m, const std::string &name, in
         for (int q = 0; q < 8; ++q)
             for (int o = 0; o < 2; ++o)
                 for (int j = 0; j < 4; ++j)
-                    h[(((size_t)t * 8 + q) * 2 + o) * 4 + j] = w->data[((size_t)o * 32 + 4 * q + j) * k * k + t];
+                    h[(((size_t)t * 8 + q) * 4 + j) * 2 + o] = w->data[((size_t)o * 32 + 4 * q + j) * k * k + t];
     bias[0] = b->data[0];
     bias[1] = b->data[1];
     return upload(net, h, dev);
