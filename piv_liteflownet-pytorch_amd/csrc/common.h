@@ -115,6 +115,7 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);
+int launch_splitk_reduce(const ConvParams &p, int nz, hipStream_t st);     // second pass of a split-K layer (also used by conv_split.hip)
 
 // ---- fp16-multiplicand variant (conv_f16.hip): optional reduced-precision mode, K chunks of 16 channels ----------------
 struct ConvSegH {
@@ -147,6 +148,9 @@ struct ConvParamsX {
     int out_stride, cout_store, cout_pad;
     float out_scale;    // 2^-k: undoes the power-of-two scale of the packed weights
     int terms;          // partial products per product: 6 (exact to 2^-32) or 3 (h.h, h.m, m.h: 2^-21)
+    float *scratch;     // split-K scratch [z][pixel][cout_pad] (nullptr: never split); the policy is in launch_conv_x
+    size_t scratch_floats;
+    int ksplit;         // set by the launcher
     int B, H, W, Ho, Wo;
     int KH, KW, S, padY, padX;
     int nchunk, lrelu;

@@ -435,6 +435,14 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
     *reinterpret_cast<f32x4 *>(p.out + (size_t)pix * p.out_stride + ch) = v;
 }
 
+int launch_splitk_reduce(const ConvParams &p, int nz, hipStream_t st)
+{
+    const long items = (long)p.B * p.Ho * p.Wo * (p.cout_pad / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, nz);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
 template <int MT, int NT, int PMAX, int WMAX>
 static int launch_t2(const ConvParams &p, hipStream_t st)
 {

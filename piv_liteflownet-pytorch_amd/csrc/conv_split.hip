@@ -151,11 +151,23 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
     const h8 k22 = {(_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f,
                     (_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f, (_Float16)0x1p-22f};
 
+    // this workgroup's K range: all chunks, or with split-K (gridDim.z > 1) an even share of them
+    const int nz = gridDim.z, kz = blockIdx.z;
+    const int c_begin = (int)((long)p.nchunk * kz / nz), c_end = (int)((long)p.nchunk * (kz + 1) / nz);
+    for (int c = 0; c < c_begin; ++c) {     // walk the sources to the first chunk of the share
+        c0 += 16;
+        if (c0 >= scl) {
+            ++seg;
+            c0 = 0;
+            sp = p.seg[seg].ptr;
+            scl = p.seg[seg].cload; sst = p.seg[seg].stride;
+        }
+    }
     X_LOAD_PATCH();
-    X_LOAD_W(0);
-    const int nrows = p.nchunk * p.KH;      // (chunk, ky) phases
-    int phase = 0;
-    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    X_LOAD_W(c_begin * p.KH);
+    const int nrows = c_end * p.KH;         // (chunk, ky) phases, absolute row index into the packed weights
+    int phase = c_begin * p.KH;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // registers -> LDS: split this chunk's fp32 patch into its three fp16 pieces (the previous chunk's last barrier has
         // been passed by every wave: the patch buffer is free)
         if (!(p.dbg & 4)) {
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
                     if (tid + 256 * i < nw) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
             }
             __syncthreads();
-            if (ky == 0 && chunk + 1 < p.nchunk) {
+            if (ky == 0 && chunk + 1 < c_end) {
                 c0 += 16;
                 if (c0 >= scl) {
                     ++seg;
@@ -239,6 +251,30 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
 #undef X_LOAD_W
 
     // Epilogue: lane&31 = pixel, registers 4g..4g+3 = channels 8g + 4*hh + {0..3} (the D layout of the 32x32 instructions).
+    if (nz > 1) {
+        // split-K: this share's partial sums (already scaled back) to scratch[z][pixel][cout_pad]; conv_splitk_reduce_kernel adds
+        // the shares in z order, then bias and activation
+        const int ox = x0 + row;
+        const size_t npix = (size_t)p.B * p.Ho * p.Wo;
+        const float sc = p.out_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + wave * MT + m;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            float *dst = p.scratch + ((size_t)kz * npix + (size_t)(b * p.Ho + oy) * p.Wo + ox) * p.cout_pad;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n0 + n * 32 + 8 * g + 4 * hh;
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * g + j] * sc;
+                    *reinterpret_cast<f32x4 *>(dst + ch) = v;
+                }
+        }
+        return;
+    }
     {
         const int ox = x0 + row;
         const bool interior = x0 + 32 <= p.Wo && y0 + TH <= p.Ho && n0 + BN <= p.cout_store;
@@ -279,9 +315,17 @@ static int launch_x(const ConvParamsX &p, hipStream_t st)
     static LdsAttr attr;
     if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_split_kernel<TERMS, MT, NT, PM, WM, OCC>), 160 * 1024)) return rc;
     const int tiles = cdiv(p.Wo, 32) * cdiv(p.Ho, TH) * p.B;
-    dim3 grid(tiles, p.cout_pad / BN);
+    const int nz = p.ksplit > 1 ? p.ksplit : 1;
+    dim3 grid(tiles, p.cout_pad / BN, nz);
     hipLaunchKernelGGL((conv_split_kernel<TERMS, MT, NT, PM, WM, OCC>), grid, dim3(256), lds, st, p);
     PIV_CHECK_HIP(hipGetLastError());
+    if (nz > 1) {       // second pass: the fp32 kernel's reduction (conv_mfma.hip)
+        ConvParams r;
+        memset(&r, 0, sizeof(r));
+        r.scratch = p.scratch; r.bias = p.bias; r.out = p.out; r.out_stride = p.out_stride; r.cout_store = p.cout_store;
+        r.cout_pad = p.cout_pad; r.B = p.B; r.Ho = p.Ho; r.Wo = p.Wo; r.lrelu = p.lrelu;
+        return launch_splitk_reduce(r, nz, st);
+    }
     return PIVLFN_OK;
 }
 
@@ -569,7 +613,24 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
     PIV_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.B > 0, "conv_split: empty output");
     if (PIV_KNOB(1) & 65536) p.terms = 3;     // tools: three-term products whatever the caller asked for
     PIV_REQUIRE(conv_split_supports(p.KH, p.KW, p.S, p.cout_pad, p.terms), "conv_split: unsupported geometry k=%dx%d stride %d with %d-term products", p.KH, p.KW, p.S, p.terms);
+    // Split-K for grids with too few tiles for the chip (the coarse pyramid levels): decided from the per-image count of canonical
+    // (4 rows x 32 px x 32 channels) tiles and the chunk count only, never from the batch or the tile shape -- the summation
+    // order, hence the bits, of a pair must not depend on its batch mates.
+    p.ksplit = 1;
+    {
+        const long blocks1 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 4) * (p.cout_pad / 32);
+        if (p.scratch && p.terms == 3 && p.S == 1 && blocks1 <= 256 && p.nchunk >= 2) {
+            p.ksplit = (int)std::min<long>(std::min(8, p.nchunk), std::max<long>(1, 1024 / blocks1));
+            if ((size_t)p.B * p.Ho * p.Wo * p.cout_pad * p.ksplit > p.scratch_floats) p.ksplit = 1;
+        }
+    }
     if (p.S == 2) return p.cout_pad % 64 == 0 ? launch_x<3, 1, 2, 5, 3, 2>(p, st) : launch_x<3, 1, 1, 5, 2, 2>(p, st);
+    // small grids (three-term, 3 x 3 or smaller kernels): 4-row tiles while 8-row ones would leave CUs without work
+    if (p.terms == 3 && p.KH <= 3 && p.KW <= 3) {
+        const long t8 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B * p.ksplit;
+        if (p.cout_pad % 64 == 0 && t8 * (p.cout_pad / 64) < 512) return launch_x<3, 1, 2, 2, 3, 4>(p, st);
+        if (p.cout_pad % 64 != 0 && t8 * (p.cout_pad / 32) < 512) return launch_x<3, 1, 1, 2, 2, 4>(p, st);
+    }
     const bool wide = p.KW > 3;                       // 1 x k / k x k rows of 5 or 7 taps: the larger weight-row class
     const bool tall = (7 + p.KH) * (31 + p.KW) * 2 > 256 * 3;
     if (p.terms == 3) {
@@ -577,10 +638,10 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
         // results; 128->128 at 1024^2: 841 -> 769 us, at 512^2: 221 -> 196; fewer tiles or chunks: its prologue does not pay)
         const long t16 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 16) * p.B;
         const bool fits31 = (size_t)p.H * p.W * 4 * 160 < ((size_t)1 << 31);      // 32-bit buffer offsets inside one image
-        if (p.cout_pad % 128 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 128) >= 512 && p.nchunk >= 6 && fits31 &&
+        if (p.ksplit == 1 && p.cout_pad % 128 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 128) >= 512 && p.nchunk >= 6 && fits31 &&
             !(PIV_KNOB(1) & 262144))
             return launch_xbig<4>(p, st);
-        if (p.cout_pad % 64 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 64) >= 512 && p.nchunk >= 6 && fits31 &&
+        if (p.ksplit == 1 && p.cout_pad % 64 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 64) >= 512 && p.nchunk >= 6 && fits31 &&
             !(PIV_KNOB(1) & 131072))
             return launch_xbig<2>(p, st);       // 128->64 at 1024^2: 476 -> 445 us
         // 128-channel tiles unless that leaves fewer than four workgroups per CU (tile shapes never change a result's bits)

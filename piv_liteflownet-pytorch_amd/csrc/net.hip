@@ -505,12 +505,12 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         return launch_conv_h(q, st);
     }
     PIV_REQUIRE(!in16 && !out16, "internal: fp16 activations routed to the fp32 conv kernel");
-    // split modes: every residual-free stride-1 conv with an output grid of at least 256x256 per image runs on the fp16 matrix
-    // cores with split fp32 operands (conv_split.hip); coarser grids have too few 8-row tiles for its two workgroups per CU and
-    // stay on the fp32 instruction kernel (measured at 1024^2, 512^2 and 256^2: tools/split_threshold.py).  Per image: the
-    // choice never depends on the batch.
+    // split modes: every residual-free conv the split kernel covers, with an output grid of at least 64x64 per image (the three-term
+    // kernel has 4-row tiles and split-K for the small grids; below 64x64 the layers are a dependent chain of ~12 us launches on
+    // either kernel).  The six-term kernel has neither and keeps the 256x256 bound.  Per image: the choice never depends on the
+    // batch (tools/split_threshold.py: 1024^2, 512^2 and 256^2 inputs).
     if (t_precision >= 2 && !res && cw.wpk_x && conv_split_supports(cw.KH, cw.KW, S, cw.cout_pad, t_precision == 3 ? 3 : 6) &&
-        (long)Ho * Wo >= (PIV_KNOB(11) ? PIV_KNOB(11) : 256 * 256)) {
+        (long)Ho * Wo >= (PIV_KNOB(11) ? PIV_KNOB(11) : (t_precision == 3 ? 64 * 64 : 256 * 256))) {
         ConvParamsX q;
         memset(&q, 0, sizeof(q));
         int i = 0;
@@ -521,6 +521,8 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         q.B = B; q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
         q.KH = cw.KH; q.KW = cw.KW; q.S = S; q.padY = padY; q.padX = padX;
         q.nchunk = cw.nchunk_x; q.lrelu = lrelu;
+        q.scratch = (t_side && st == t_side) ? nullptr : t_scratch;      // one scratch area: the side stream never splits
+        q.scratch_floats = KSPLIT_FLOATS * B;
         return launch_conv_x(q, st);
     }
     ConvParams p;
@@ -592,6 +594,7 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     q.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
     q.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
     q.nchunk = c->cw.nchunk_x; q.lrelu = leaky;
+    q.scratch = c->scratch; q.scratch_floats = KSPLIT_FLOATS;
     return launch_conv_x(q, st);
 }
 

@@ -186,9 +186,10 @@ def test_split_modes_meet_the_fp32_tolerance_against_the_oracle(model, size, mod
     assert np.array_equal(net(x1.to(dev), x2.to(dev)).cpu().numpy(), f32)     # switching back restores the bits
 
 
-def test_small_grids_never_reach_the_split_kernel(gold, dev):
-    """Golden 96 x 160 case (flows produced by the reference itself): no level has 256 x 256 outputs, so every fp32 mode is the
-    fp32 instruction path, bit for bit -- and meets the bars against the reference's flows."""
+def test_golden_case_small_grids(gold, dev):
+    """Golden 96 x 160 case (flows produced by the reference itself).  No level has 256 x 256 outputs, so the six-term mode is the
+    fp32 instruction path bit for bit; the three-term mode runs level 1 (96 x 160 >= 64 x 64) on its 4-row tiles and meets the
+    same bars against the reference's flows."""
     g = gold["e2e_cases"]
     tag = "piv_2x96x160"
     i1 = torch.from_numpy(np.stack([synth.to_input(a) for a in g[f"{tag}_img1"]])).to(dev)
@@ -198,8 +199,26 @@ def test_small_grids_never_reach_the_split_kernel(gold, dev):
     for mode in ("fp32", "fp32_split", "fp32_split3"):
         net.precision = mode
         outs[mode] = net(i1, i2).cpu().numpy()
-    assert np.array_equal(outs["fp32"], outs["fp32_split"]) and np.array_equal(outs["fp32"], outs["fp32_split3"])
-    _check(outs["fp32_split3"], g[f"{tag}_flow"], f"{tag} vs reference flows")
+    assert np.array_equal(outs["fp32"], outs["fp32_split"]) and not np.array_equal(outs["fp32"], outs["fp32_split3"])
+    _check(outs["fp32"], g[f"{tag}_flow"], f"{tag} fp32 instruction vs reference flows")
+    _check(outs["fp32_split3"], g[f"{tag}_flow"], f"{tag} three-term split vs reference flows")
+
+
+@pytest.mark.parametrize("size", [(64, 64), (128, 160), (192, 256)])
+def test_three_term_mode_small_levels_split_k(size, dev):
+    """Coarse levels on the three-term kernel's split-K path (64 x 64 ... 128 x 128 grids): against the oracle, and the same bits
+    alone and in a batch of three."""
+    H, W = size
+    a, b = synth.particle_batch(3, H * 2, W * 2, seed=31 + H)
+    i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    full = net(i1, i2)
+    for k in range(3):
+        assert torch.equal(net(i1[k:k + 1], i2[k:k + 1])[0], full[k])
+    onet = orc.make_net("piv", synth.generate_weights("piv", 0), corr="c")
+    with torch.no_grad():
+        want = onet.forward(torch.from_numpy(a[:1]), torch.from_numpy(b[:1])).numpy()
+    _check(full[:1].cpu().numpy(), want, f"piv {2 * H}x{2 * W} three-term split (levels down to {H // 8}x{W // 8} on split-K) vs oracle")
 
 
 @pytest.mark.parametrize("mode", ["fp32_split3", "fp32_split"])
