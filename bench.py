@@ -148,10 +148,56 @@ def arithmetic_modes(net, i1, i2, steps, dev):
         res[mode] = {"pairs_per_s": round(steps * i1.shape[0] / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
                      "max_abs_px_vs_fp32_instruction": round(float((flow - ref).abs().max()), 7)}
     net.precision = keep
-    res["what"] = ("fp32 = v_mfma_f32_32x32x2_f32 on every conv; fp32_split / fp32_split3 = stride-1 convs with >= 256x256 outputs on "
-                   "v_mfma_f32_32x32x16_f16 with fp32 operands split into 3 / 2 fp16 pieces (6 / 3 partial products, fp32 accumulate); "
+    res["what"] = ("fp32 = v_mfma_f32_32x32x2_f32 on every conv; fp32_split / fp32_split3 = the residual-free convs with >= 256x256 / "
+                   ">= 64x64 outputs per image on v_mfma_f32_32x32x16_f16 with fp32 operands split into 3 / 2 fp16 pieces (6 / 3 partial "
+                   "products, fp32 accumulate); "
                    "layer-output error against float64 (tests/test_gpu_split.py): both splits 0.6 x the fp32 instruction's")
     return res
+
+
+def conv_roofline(dev, precision, launches=10):
+    """The dominant kernel of the forward -- the 128 -> 128 3x3 convolution of level 1 (1024 x 1024, batch 1) -- standalone through
+    the C ABI: matrix-core work actually executed per launch / its duration, against the dense MFMA peak of the instruction used."""
+    import ctypes
+    from pivlfn import _lib
+    lib = _lib.load()
+    co = ci = 128
+    n = 1024
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).contiguous()
+    b = torch.randn(co, generator=g).contiguous()
+    h = ctypes.c_void_p()
+    _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(h)), "conv_create")
+    x = torch.randn(1, n, n, ci, device=dev)
+    y = torch.empty(1, n, n, co, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    terms = {"fp32_split3": 3, "fp32_split": 6}.get(precision, 0)
+
+    def launch():
+        if terms:
+            _lib.check(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), ci, y.data_ptr(), co, 1, n, n, 1, 1, 1, 1, terms, st), "conv")
+        else:
+            _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), co, None, 0, 1, n, n, 1, 1, 1, 1, st), "conv")
+    for _ in range(5):
+        launch()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(launches):
+        launch()
+    e.record()
+    torch.cuda.synchronize(dev)
+    lib.pivlfn_conv_destroy(h)
+    t = a.elapsed_time(e) / launches * 1e-3
+    flop = 2.0 * n * n * co * ci * 9
+    if terms:
+        return {"bound": "mfma", "achieved": round(terms * flop / t / 1e12, 1), "peak": 2516.0, "unit": "TFLOP/s", "frac": round(terms * flop / t / 2.516e15, 4),
+                "traffic": None, "kernel": f"conv_split kernels, 128->128 3x3 at 1024x1024 B=1, {terms} fp16 partial products per fp32 product (v_mfma_f32_32x32x16_f16)",
+                "fp32_equivalent_tflops": round(flop / t / 1e12, 1), "avg_launch_us": round(t * 1e6, 1), "launches_timed": launches,
+                "sustainable_on_random_operands_tflops": 1600.0,
+                "note": "fp16 matrix work actually executed (terms x 2 x pixels x Cin x Cout x 9) / duration; the chip sustains ~1600 TFLOP/s of this "
+                        "instruction on random operands (1.70 GHz under power, tools/micro/mfma_f16_power.hip, profiles/r02_mfma_f16_power.log)"}
+    return {"bound": "mfma", "achieved": round(flop / t / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(flop / t / 157.3e12, 4), "traffic": None,
+            "kernel": "conv_mfma2_kernel, 128->128 3x3 at 1024x1024 B=1 (v_mfma_f32_32x32x2_f32)", "avg_launch_us": round(t * 1e6, 1), "launches_timed": launches}
 
 
 def l3_throughput_regime(dev, batch=8, launches=40):
@@ -325,7 +371,7 @@ def main():
                        "pairs_per_step_per_gpu": B, "weights": "generated (pivlfn.synth seed 0)",
                        "multi_gpu": "pairs sharded over ranks, async RCCL all-gather of flows per step" if world > 1 else "single GPU"},
             "roofline": roof,
-            "whole_net": {"conv_tflops": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
+            "whole_net": {"conv_tflops_fp32_equivalent": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
                           "fp32_mfma_peak_tflops": 157.3,
                           # against the fp32 instruction's peak: above 1 means the split path beats what that instruction can do at all
                           "compute_frac": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None,
@@ -344,6 +390,8 @@ def main():
                                       "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2]}
         if world == 1 and args.model == "piv" and S == 1024:
             out["roofline_batch8"] = l3_throughput_regime(dev)
+        if world == 1 and fp32_grade and args.model == "piv" and S == 1024:
+            out["roofline_conv"] = conv_roofline(dev, args.precision)
         if world == 1 and fp32_grade and not args.no_arithmetic:
             out["arithmetic"] = arithmetic_modes(net, i1, i2, min(args.steps, 10), dev)
         if not args.no_cpu_baseline and world == 1:

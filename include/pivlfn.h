@@ -109,12 +109,15 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
  * pieces (11 + 11 + 2 significand bits at scales 1, 2^-11, 2^-22) and each product is formed from six exact fp16 x fp16
  * products accumulated in fp32; what is dropped is below 2^-32 of a product, 256 x under the rounding of an fp32 fma
  * (csrc/conv_split.hip; tests/test_gpu_split.py measures the error against float64 next to the fp32 instruction's).
- * Applies to the stride-1 convolutions with an output grid of at least 64 x 64; everything else runs as in F32. */
+ * Applies to the residual-free stride-1 convolutions with an output grid of at least 256 x 256 per image; everything else runs
+ * as in F32.  Inputs of those layers must stay below 65504 in magnitude (fp16 range of the leading piece; beyond it the
+ * result is NaN, not a silently saturated value). */
 #define PIVLFN_PRECISION_F32_SPLIT 2
 /* PIVLFN_PRECISION_F32_SPLIT3: the same with two pieces per operand and the three leading partial products (h.h, h.m, m.h):
  * a product carries a relative error of at most 2^-21 (typically 2^-23.5, about one fp32 ulp on each operand); measured against
  * float64 the layer outputs are as accurate as SPLIT's and more accurate than the fp32 instruction's (fewer roundings in the
- * accumulation), at half the matrix work. */
+ * accumulation), at half the matrix work.  Applies to the residual-free convolutions with an output grid of at least 64 x 64 per
+ * image: stride 1 (4-row tiles and split-K on the small grids) and 3 x 3 stride 2.  The library's default. */
 #define PIVLFN_PRECISION_F32_SPLIT3 3
 int pivlfn_set_precision(pivlfn_net *net, int precision);
 

@@ -115,6 +115,7 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);
+int launch_touch(const float *p, size_t floats, float *sink, hipStream_t st);     // read-only prefetch pass (ops.hip)
 int launch_splitk_reduce(const ConvParams &p, int nz, hipStream_t st);     // second pass of a split-K layer (also used by conv_split.hip)
 
 // ---- fp16-multiplicand variant (conv_f16.hip): optional reduced-precision mode, K chunks of 16 channels ----------------

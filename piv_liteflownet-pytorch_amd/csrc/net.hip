@@ -659,6 +659,12 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     RUN(conv(nc[9], {{bf.feat[5], 128, 128}}, bf.feat[6], 192, 192, nullptr, 0, 1, N2, h[5], w[5], 2, 1, 1, st));
     if (!side_early)
         for (int L = 4; L >= net->lowest; --L) RUN(side_level(L));
+    // The side stream's 1x1 outputs (1.5 GB at 1024^2) pass through the Infinity Cache after NetC wrote the level-3 features and
+    // push them out; the level-3 warp+correlation -- one tile per CU, nothing to overlap a miss with -- then gathers from HBM.  A
+    // read-only pass over those features at the tail of the side stream (it runs beside levels 6-4, which use a fraction of the
+    // chip) brings them back.  No join: nothing depends on it.
+    if (side != st && net->lowest <= 3 && !(PIV_KNOB(1) & 16384))
+        RUN(launch_touch(bf.feat[3], N2 * h[3] * w[3] * C_FEAT[3], bf.mean, side));
 
     float *prev = nullptr, *cur = bf.flowA;
     size_t lvoff = 0;
