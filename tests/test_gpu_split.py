@@ -29,6 +29,7 @@ LAYERS = [(128, 128, 3, 3, 1, 128, 128),   # <2,2> twice over the channels
           (128, 128, 3, 3, 2, 272, 1024),  # enough 16-row tiles for the one-workgroup-per-CU kernel (three terms), ragged in y
           (64, 132, 3, 3, 1, 544, 512),    # the same with 64 channels and a 4-channel K tail
           (256, 96, 3, 3, 1, 256, 544),    # two 128-channel blocks
+          (128, 100, 3, 3, 1, 530, 500),   # the same kernel with ragged tiles in x and y and a 4-channel K tail
           (64, 128, 3, 3, 2, 64, 96),
           (64, 64, 3, 3, 1, 72, 100),      # ragged edges
           (32, 64, 3, 3, 1, 64, 64),       # <2,1>

@@ -106,7 +106,7 @@ def bench_wc_ablate(args):
         fl[..., :2] = torch.randn(B, n, n, 2, device=dev) * 0.8
         no = -(-n // s)
         out = torch.empty(B, no, no, 56, device=dev)
-        for mask in (0, 8, 1, 2, 4, 3, 7):
+        for mask in [int(m) for m in args.masks.split(",")]:
             def fn():
                 _chk(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), fl.data_ptr() if L < 6 else None, 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
             lib.pivlfn_tune(2, mask)
@@ -294,6 +294,7 @@ if __name__ == "__main__":
     ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
     ap.add_argument("--variants", default="6,8,5")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
+    ap.add_argument("--masks", default="0,8,1,2,4,3,7", help="wc_ablate: pivlfn_tune(2, .) masks")
     ap.add_argument("--rounds", type=int, default=8, help="interleaved timing rounds per variant (warp_corr)")
     a = ap.parse_args()
     {"conv_stamps": bench_conv_stamps, "warp_corr": bench_warp_corr, "wc_ablate": bench_wc_ablate, "conv": bench_conv, "head": bench_head}[a.what](a)
