@@ -662,9 +662,13 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     // The side stream's 1x1 outputs (1.5 GB at 1024^2) pass through the Infinity Cache after NetC wrote the level-3 features and
     // push them out; the level-3 warp+correlation -- one tile per CU, nothing to overlap a miss with -- then gathers from HBM.  A
     // read-only pass over those features at the tail of the side stream (it runs beside levels 6-4, which use a fraction of the
-    // chip) brings them back.  No join: nothing depends on it.
-    if (side != st && net->lowest <= 3 && !(PIV_KNOB(1) & 16384))
+    // chip) brings them back.  Nothing depends on it; it is joined at the end of the forward.
+    bool touched = false;
+    if (side != st && net->lowest <= 3 && !(PIV_KNOB(1) & 16384)) {
         RUN(launch_touch(bf.feat[3], N2 * h[3] * w[3] * C_FEAT[3], bf.mean, side));
+        PIV_CHECK_HIP(hipEventRecord(net->ev_join[6], side));      // joined at the very end of the forward (stream capture needs it)
+        touched = true;
+    }
 
     float *prev = nullptr, *cur = bf.flowA;
     size_t lvoff = 0;
@@ -776,6 +780,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         prev = cur;
         cur = (cur == bf.flowA) ? bf.flowB : bf.flowA;
     }
+    if (touched) PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[6], 0));
 #undef RUN
     return PIVLFN_OK;
 }
