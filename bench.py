@@ -374,7 +374,7 @@ def main():
             "whole_net": {"conv_tflops_fp32_equivalent": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
                           "fp32_mfma_peak_tflops": 157.3,
                           # against the fp32 instruction's peak: above 1 means the split path beats what that instruction can do at all
-                          "compute_frac": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None,
+                          "ratio_to_fp32_mfma_peak": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None,
                           # layer-boundary bytes of the reference's graph (in + out + weights of every conv, fp32)
                           "layer_boundary_gb_per_pair": 16.57 if (args.model == 'piv' and S == 1024) else None,
                           "hbm_frac_of_8tbs": round(value / world * 16.57 / 8000.0, 4) if (args.model == 'piv' and S == 1024) else None},

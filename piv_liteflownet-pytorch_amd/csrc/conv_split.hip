@@ -611,7 +611,9 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
     for (int i = 0; i < p.nseg; ++i)
         PIV_REQUIRE(p.seg[i].ptr && p.seg[i].cload % 4 == 0 && p.seg[i].stride % 4 == 0, "conv_split: source %d must be 16-byte granular", i);
     PIV_REQUIRE(p.Ho > 0 && p.Wo > 0 && p.B > 0, "conv_split: empty output");
-    if (PIV_KNOB(1) & 65536) p.terms = 3;     // tools: three-term products whatever the caller asked for
+    // tools-build knobs (pivlfn_tune(1, .); all zero in libpivlfn.so): 65536 force three terms, 131072 / 262144 no 16-row kernel for
+    // 64 / 128 channels, 524288 no 16-row small-kernel tiles for 64 channels
+    if (PIV_KNOB(1) & 65536) p.terms = 3;
     PIV_REQUIRE(conv_split_supports(p.KH, p.KW, p.S, p.cout_pad, p.terms), "conv_split: unsupported geometry k=%dx%d stride %d with %d-term products", p.KH, p.KW, p.S, p.terms);
     // Split-K for grids with too few tiles for the chip (the coarse pyramid levels): decided from the per-image count of canonical
     // (4 rows x 32 px x 32 channels) tiles and the chunk count only, never from the batch or the tile shape -- the summation
