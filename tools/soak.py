@@ -17,9 +17,10 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device("cuda:0")
 nets = {(m, v): pivlfn.Network(model=m, params=synth.generate_weights(m + ("2" if v == 2 else ""), 0), version=v).to(dev).eval()
         for m, v in [("piv", 1), ("hui", 1), ("piv", 2)]}
-cfgs = [(("piv", 1), 1, 256, 256, "fp32"), (("piv", 1), 3, 96, 160, "fp32"), (("hui", 1), 2, 128, 192, "fp32"),
-        (("piv", 2), 1, 192, 128, "fp32"), (("piv", 1), 1, 512, 384, "fp16"), (("piv", 1), 2, 64, 64, "fp32"),
-        (("hui", 1), 1, 320, 256, "fp16"), (("piv", 1), 5, 128, 128, "fp32"), (("piv", 1), 1, 1024, 1024, "fp32")]
+cfgs = [(("piv", 1), 1, 256, 256, "fp32_split3"), (("piv", 1), 3, 96, 160, "fp32"), (("hui", 1), 2, 128, 192, "fp32_split3"),
+        (("piv", 2), 1, 192, 128, "fp32_split"), (("piv", 1), 1, 512, 384, "fp16"), (("piv", 1), 2, 64, 64, "fp32_split3"),
+        (("hui", 1), 1, 320, 256, "fp16"), (("piv", 1), 5, 128, 128, "fp32_split3"), (("piv", 1), 1, 1024, 1024, "fp32_split3"),
+        (("piv", 1), 2, 1024, 512, "fp32_split"), (("hui", 1), 1, 544, 800, "fp32_split3"), (("piv", 2), 2, 512, 512, "fp32_split3")]
 inputs, first = {}, {}
 for i, (key, B, H, W, prec) in enumerate(cfgs):
     a, b = synth.particle_batch(B, H, W, seed=70 + i)
