@@ -623,12 +623,14 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     RUN(launch_prep_images(img1, img2, bf.img[1], B, H, W, net->mean, st));
     for (int L = 2; L <= 6; ++L) RUN(launch_resize_nhwc4(bf.img[L - 1], bf.img[L], N2, h[L - 1], w[L - 1], h[L], w[L], st));
     // Flow-independent 1x1 convs on the side stream: NetC_ext (:353-355) for levels <= 2 and Regularization.moduleFeat (:227-232,
-    // applied at :280) for levels < 5.  Each level's share is issued as soon as NetC has produced that level's feature map, so the
-    // HBM-bound 1x1 work overlaps the rest of NetC (large MFMA-bound grids) instead of the latency-bound chains of tiny kernels of
-    // levels 6-4, which lose most when CUs are taken away from them (the level-5 warp+correlation, a whole CU per tile, waited
-    // 80 us for a free CU behind the level-1 share).
+    // applied at :280) for levels < 5; 1.8 GB of HBM traffic at 1024^2.  Where they run is a trade: beside NetC they slow its
+    // MFMA-bound kernels and push the level-3 features out of the Infinity Cache; beside levels 6-4 those chains of tiny kernels
+    // wait for CUs (the level-5 warp+correlation 15 -> 40 us).  Round 2, early: issued per level as soon as NetC had produced the
+    // level's features (the level-3 launch gained 2.6 us).  Late round 2: the conv stacks are twice as fast, the prefetch pass below
+    // restores the level-3 features whatever the order, and all of it after NetC is the faster step (10.58 vs 10.70 ms,
+    // tools/net_ab.py --masks 0,4096, three interleaved rounds) -- the default again; the early order stays selectable in the tools build.
     const hipStream_t side = (PIV_KNOB(1) & 2048) ? st : net->side;        // tools A/B: everything on one stream
-    const bool side_early = !(PIV_KNOB(1) & 4096);                         // tools A/B: 4096 = round-1 order (all of it after NetC)
+    const bool side_early = (PIV_KNOB(1) & 4096) != 0;                     // tools A/B: 4096 = each level's share right behind its NetC layer
     auto side_level = [&](int L) -> int {
         if (L < net->lowest || L > 4) return PIVLFN_OK;
         if (side != st) {
