@@ -61,6 +61,9 @@ parser.add_argument("--no_cuda", action="store_true")
 parser.add_argument("--weights", type=str, default=None, help="state dict file (torch.load); default: seeded synthetic weights")
 parser.add_argument("--synthetic_weights", action="store_true")
 parser.add_argument("--batch", type=int, default=4, help="pairs per forward")
+parser.add_argument("--precision", type=str, default=None, choices=["fp32_split3", "fp32_split", "fp32", "fp16"],
+                    help="how the large convolutions multiply (not a reference flag; default: the library's, fp32_split3 -- "
+                         "see Network.precision)")
 
 
 @dataclass(frozen=True)
@@ -170,6 +173,8 @@ def main(argv: Optional[List[str]] = None) -> int:
     torch.cuda.set_device(device)
     weights, netname = load_weights(args)
     net = Network(model=args.model, params=weights, version=args.version).to(device).eval()
+    if args.precision is not None:
+        net.precision = args.precision
     mods = None
     if args.brightness is not None or args.contrast is not None:
         mods = list(product(tuple(args.brightness or (1.0,)), tuple(args.contrast or (1.0,))))
