@@ -118,13 +118,16 @@ def counter_traffic(name):
     return j.get("hbm_bytes_per_launch"), f"profiles/{name}"
 
 
-DTYPE = {
-    "fp32_split3": "f32 (fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as "
-                   "two fp16 pieces: 3 partial products per fp32 product, relative product error <= 2^-21; see `arithmetic`)",
-    "fp32_split": "f32 (fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as "
-                  "three fp16 pieces: 6 partial products per fp32 product, exact to 2^-32; see `arithmetic`)",
-    "fp32": "f32",
-    "fp16": "f16 multiplicands, f32 accumulate",
+DTYPE = {       # the arithmetic type the path computes in (short), and what that means (dtype_note)
+    "fp32_split3": ("f32 (products from fp16x3 split operands on the f16 MFMA, f32 accumulate)",
+                    "fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as two fp16 "
+                    "pieces: 3 partial products per fp32 product, relative product error <= 2^-21, layer outputs closer to float64 than the "
+                    "fp32 matrix instruction's; `arithmetic` times the fp32 instruction path in the same run"),
+    "fp32_split": ("f32 (products from fp16x6 split operands on the f16 MFMA, f32 accumulate)",
+                   "fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as three fp16 "
+                   "pieces: 6 partial products per fp32 product, exact to 2^-32; `arithmetic` times the fp32 instruction path in the same run"),
+    "fp32": ("f32", "v_mfma_f32_32x32x2_f32 in every convolution"),
+    "fp16": ("f16 multiplicands, f32 accumulate", "BASELINE config #5: operands rounded to fp16"),
 }
 
 
@@ -364,7 +367,7 @@ def main():
                         f" image-pairs/s at {S}x{S}, fp16-multiplicand conv mode (BASELINE config #5 variant; not the fp32 headline)")),
             "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[args.precision][0], "dtype_note": DTYPE[args.precision][1], "data": "synthetic",
             "config": {"workload": f"{'PIV-LiteFlowNet-en' if args.model == 'piv' else 'LiteFlowNet'} forward, batch {B}/GPU, "
                                    f"{S}x{S} synthetic PIV pair, " + ("fp32 (BASELINE configs[1])" if fp32_grade else "fp16-multiplicand convs"),
                        "conv_arithmetic": args.precision,
