@@ -111,7 +111,8 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
  * (csrc/conv_split.hip; tests/test_gpu_split.py measures the error against float64 next to the fp32 instruction's).
  * Applies to the residual-free stride-1 convolutions with an output grid of at least 256 x 256 per image; everything else runs
  * as in F32.  Inputs of those layers must stay below 65504 in magnitude (fp16 range of the leading piece; beyond it the
- * result is NaN, not a silently saturated value). */
+ * result is NaN, not a silently saturated value); inputs below 2^-14 in magnitude are represented to an absolute 2^-37
+ * (2^-26 in SPLIT3) instead of exactly. */
 #define PIVLFN_PRECISION_F32_SPLIT 2
 /* PIVLFN_PRECISION_F32_SPLIT3: the same with two pieces per operand and the three leading partial products (h.h, h.m, m.h):
  * a product carries a relative error of at most 2^-21 (typically 2^-23.5, about one fp32 ulp on each operand); measured against

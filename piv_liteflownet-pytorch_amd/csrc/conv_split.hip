@@ -5,7 +5,8 @@
 //
 //     x = h + m * 2^-11 + l * 2^-22,     h = rn16(x),  m = rn16((x - h) * 2^11),  l = rn16(((x - h) * 2^11 - m) * 2^11)
 //
-// (11 + 11 + 2 significand bits; every subtraction is exact in fp32), so a product of two fp32 numbers is the sum of nine
+// (11 + 11 + 2 significand bits; every subtraction is exact in fp32; exact for 2^-14 <= |x| < 65504 -- below 2^-14 the conversion
+// flushes h and the other pieces carry 22 bits: |error| < 2^-37), so a product of two fp32 numbers is the sum of nine
 // fp16 x fp16 products, each exact in the fp32 the matrix core accumulates in.  Six of them carry everything above 2^-33 of the
 // product:  h.h | h.m 2^-11, m.h 2^-11 | m.m 2^-22, h.l 2^-22, l.h 2^-22;  the three dropped ones are <= 2^-32 relative -- 256 x
 // below the rounding an fp32 fma chain itself commits per step.  The sum over K and over the six terms is accumulated in fp32

@@ -232,3 +232,73 @@ def test_split_mode_batch_consistency(mode, dev):
     full = net(i1, i2)
     for k in range(3):
         assert torch.equal(net(i1[k:k + 1], i2[k:k + 1])[0], full[k])
+
+
+# ---- exactness and size-independent properties ---------------------------------------------------------------------------
+def _conv_split(w, b, x, terms, dev, leaky=0):
+    co, ci, kh, kw = w.shape
+    B, H, W, xs = x.shape
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.pivlfn_conv_create(w.contiguous().data_ptr(), b.contiguous().data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
+    ys = -(-co // 4) * 4
+    y = torch.full((B, H, W, ys), float("nan"), device=dev)
+    xd = x.to(dev)
+    _lib.check(lib.pivlfn_conv2d_nhwc_split(h, xd.data_ptr(), xs, y.data_ptr(), ys, B, H, W, 1, kh // 2, kw // 2, leaky, terms,
+                                            torch.cuda.current_stream(dev).cuda_stream), "split")
+    torch.cuda.synchronize()
+    lib.pivlfn_conv_destroy(h)
+    return y.cpu()
+
+
+def test_six_term_identity_layer_returns_its_fp32_input_bit_for_bit(dev):
+    """x = h + m 2^-11 + l 2^-22 exactly for 2^-14 <= |x| < 65504: a 1 x 1 layer with the identity matrix hands back every such fp32
+    input bit -- 24 binades of magnitudes, both signs, zeros.  The three-term form returns h + m 2^-11: within 2^-21 of x.  Below
+    2^-14 (fp16's subnormal range, which the conversion flushes) the leading piece is zero and the remaining ones carry 22 (11) bits:
+    the absolute deviation stays below 2^-37 (2^-26)."""
+    C = 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 64, 96, C, generator=g).clamp(-3.9, 3.9)
+    x = torch.where(x.abs() < 0.25, torch.full_like(x, 0.5), x) * torch.exp2(torch.randint(-12, 13, (1, 64, 96, C), generator=g).float())
+    x[0, :4] = 0.0
+    assert float(x.abs().max()) < 65504 and float(x[0, 4:].abs().min()) >= 2.0 ** -14
+    w = torch.eye(C).reshape(C, C, 1, 1)
+    b = torch.zeros(C)
+    y6 = _conv_split(w, b, x, 6, dev)
+    assert torch.equal(y6, x)
+    y3 = _conv_split(w, b, x, 3, dev)
+    rel = ((y3 - x).abs() / x.abs().clamp_min(1e-30)).max().item()
+    print(f"identity layer, three terms: max relative deviation {rel:.2e} (bound 2^-21 = 4.8e-7)")
+    assert rel <= 2.0 ** -21
+    tiny = torch.randn(1, 64, 96, C, generator=g) * torch.exp2(torch.randint(-30, -14, (1, 64, 96, C), generator=g).float())
+    tiny = tiny.clamp(-2.0 ** -14 * 0.999, 2.0 ** -14 * 0.999)
+    d6 = (_conv_split(w, b, tiny, 6, dev) - tiny).abs().max().item()
+    d3 = (_conv_split(w, b, tiny, 3, dev) - tiny).abs().max().item()
+    print(f"inputs below 2^-14: max absolute deviation six terms {d6:.2e} (2^-37 = 7.3e-12), three terms {d3:.2e} (2^-26 = 1.5e-8)")
+    assert d6 <= 2.0 ** -37 and d3 <= 2.0 ** -26
+
+
+@pytest.mark.parametrize("terms", [6, 3])
+def test_split_kernel_properties_at_full_size(terms, dev):
+    """1024 x 1024, 128 -> 128, 3 x 3 (the forward's dominant layer; the 16-row kernel in the three-term form) through properties that
+    need no reference of that size: zero weights give the bias; an input shifted by a tile-unaligned offset gives the shifted output
+    in the interior, bit for bit (every tile computes every pixel the same way); scaling the input by 2 scales the pre-bias output by 2
+    exactly."""
+    C, S = 128, 1024
+    g = torch.Generator().manual_seed(21)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    b = torch.randn(C, generator=g)
+    x = torch.randn(1, S, S, C, generator=g)
+    x = torch.where(x.abs() < 1e-3, torch.full_like(x, 1e-3), x)       # away from the fp16 flush threshold (2^-14): see the identity test
+    y0 = _conv_split(torch.zeros_like(w), b, x, terms, dev)
+    assert torch.equal(y0, b.expand_as(y0))
+    zero_b = torch.zeros(C)
+    y = _conv_split(w, zero_b, x, terms, dev)
+    assert torch.isfinite(y).all()
+    dy, dx = 5, 37
+    xs = torch.zeros_like(x)
+    xs[:, dy:, dx:] = x[:, :S - dy, :S - dx]
+    ysft = _conv_split(w, zero_b, xs, terms, dev)
+    assert torch.equal(ysft[:, dy + 1:S - 1, dx + 1:S - 1], y[:, 1:S - dy - 1, 1:S - dx - 1])     # (the last row / column see the zero padding)
+    y2 = _conv_split(w, zero_b, x * 2.0, terms, dev)
+    assert torch.equal(y2, y * 2.0)
