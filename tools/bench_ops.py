@@ -103,7 +103,13 @@ def bench_wc_ablate(args):
         f1 = torch.randn(B, n, n, C, device=dev)
         f2 = torch.randn(B, n, n, C, device=dev)
         fl = torch.zeros(B, n, n, 4, device=dev)
-        fl[..., :2] = torch.randn(B, n, n, 2, device=dev) * 0.8
+        if args.smooth:      # a smooth sub-pixel flow, as the network's own are (bench.py's roofline_batch8 uses the same): every byte of f2 is touched
+            yy, xx = torch.meshgrid(torch.arange(n, device=dev, dtype=torch.float32), torch.arange(n, device=dev, dtype=torch.float32), indexing="ij")
+            ph = torch.arange(B, device=dev, dtype=torch.float32).view(B, 1, 1)
+            fl[..., 0] = 0.8 * torch.sin(yy * (6.2832 * 3 / n) + ph)
+            fl[..., 1] = 0.8 * torch.cos(xx * (6.2832 * 2 / n) + 0.5 * ph)
+        else:
+            fl[..., :2] = torch.randn(B, n, n, 2, device=dev) * 0.8
         no = -(-n // s)
         out = torch.empty(B, no, no, 56, device=dev)
         for mask in [int(m) for m in args.masks.split(",")]:
@@ -294,6 +300,7 @@ if __name__ == "__main__":
     ap.add_argument("--size", type=int, default=1024, help="input image size the level shapes are derived from")
     ap.add_argument("--variants", default="6,8,5")
     ap.add_argument("--levels", default="3,1,2,4,5,6")
+    ap.add_argument("--smooth", action="store_true", help="wc_ablate: smooth flow instead of per-pixel noise")
     ap.add_argument("--masks", default="0,8,1,2,4,3,7", help="wc_ablate: pivlfn_tune(2, .) masks")
     ap.add_argument("--rounds", type=int, default=8, help="interleaved timing rounds per variant (warp_corr)")
     a = ap.parse_args()
