@@ -161,3 +161,16 @@ def test_run_py_output_layout_and_mod_names():
     assert run.mod_flow_name("/d/frame7.png", "/o", (1.5, 1.0)) == "/o/frame7_150_100_out.flo"
     args = run.parser.parse_args(["-i", "a", "b", "-b", "0.5", "1.5", "-c", "2"])
     assert args.brightness == [0.5, 1.5] and args.contrast == [2.0] and args.model == "piv" and args.input == ["a", "b"]
+
+
+def test_precision_property_without_a_gpu():
+    """`Network.precision` is host state until the weights are uploaded: default, accepted names, refusal of anything else."""
+    import pivlfn
+    net = pivlfn.Network(model="piv")
+    assert net.precision == "fp32_split3"
+    for mode in ("fp32", "fp32_split", "fp16", "fp32_split3"):
+        net.precision = mode
+        assert net.precision == mode
+    with pytest.raises(ValueError):
+        net.precision = "bf16"
+    assert net.precision == "fp32_split3"
