@@ -144,6 +144,9 @@ struct ConvParamsX {
     ConvSeg seg[3];
     int nseg;
     const void *wpk;    // fp16 pieces [nchunk][KH*KW][3][2][cout_pad][8]
+    const void *wtail;  // 3 x 3 layers whose staged channels end in a 4-lane tail: that chunk with taps folded into K,
+                        // [step 3][piece 2][k-half 2][cout_pad][8 = 2 taps x 4 channels]; nullptr otherwise (conv_split_big_kernel)
+    int tail;           // set by the launcher: the kernel uses wtail for the last chunk
     const float *bias;  // [cout_pad]
     float *out;         // NHWC fp32
     int out_stride, cout_store, cout_pad;

@@ -441,9 +441,14 @@ __global__ __launch_bounds__(256, 1) void conv_split_big_kernel(const ConvParams
         pr[2 * (I)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0_, 0, 0));      \
         pr[2 * (I) + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o1_, 0, 0));  \
     } while (0)
-#define XB_COMMIT_ITEM(I, DST)                                                                    \
+// TL (uniform): the chunk being staged is the folded 4-channel tail -- 16-byte pixel records (h4 | m4) written by the lanes that
+// hold channels 0..3 (sub == 0); everything else goes to the spare record.  Selects, not branches: the phases stay straight-line.
+#define XB_COMMIT_ITEM(I, DST, TL)                                                                \
     do {                                                                                          \
-        _Float16 *d_ = (DST) + pdst[I];                                                           \
+        const int pixd_ = (pdst[I] - 4 * sub) / XPITCH;      /* = the item's pixel, NPIX for items that do not exist */ \
+        const int tdst_ = (sub == 0 && pixd_ < NPIX) ? pixd_ * 8 : NPIX * XPITCH;                 \
+        _Float16 *d_ = (DST) + ((TL) ? NPIX * XPITCH : pdst[I]);                                   \
+        _Float16 *dt_ = (DST) + ((TL) ? tdst_ : NPIX * XPITCH + 32);                               \
         h4 ph_[2], pm_[2];                                                                        \
         _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                        \
             const f32x4 v_ = pr[2 * (I) + e_];                                                    \
@@ -457,11 +462,17 @@ __global__ __launch_bounds__(256, 1) void conv_split_big_kernel(const ConvParams
         *reinterpret_cast<h4 *>(d_ + 8) = ph_[1];                                                 \
         *reinterpret_cast<h4 *>(d_ + 16) = pm_[0];                                                \
         *reinterpret_cast<h4 *>(d_ + 24) = pm_[1];                                                \
+        *reinterpret_cast<h4 *>(dt_) = ph_[0];                                                    \
+        *reinterpret_cast<h4 *>(dt_ + 4) = pm_[0];                                                \
     } while (0)
+// rows 0 .. 3 nfull - 1 are kernel rows of full chunks; row 3 nfull (p.tail) is the tail's slab [step][piece][k-half][cout_pad] --
+// two pieces per step packed densely, so a unit's offset is the normal one minus 2 (r >> 2) cout_pad, r >> 2 = its step
 #define XB_LOAD_W(ROWIDX)                                                                         \
     do {                                                                                          \
-        const f32x4 *wc_ = wsrc + (size_t)(ROWIDX)*wrow;                                          \
-        _Pragma("unroll") for (int i = 0; i < WM; ++i) wr[i] = wc_[wsrc_off[i]];                  \
+        const bool tl_ = p.tail && (ROWIDX) >= 3 * nfull;                                         \
+        const f32x4 *wc_ = tl_ ? wtail : wsrc + (size_t)(ROWIDX)*wrow;                            \
+        const int back_ = tl_ ? 2 * p.cout_pad : 0;                                               \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i) wr[i] = wc_[wsrc_off[i] - ((256 * i) / (4 * BN)) * back_ - (tid / (4 * BN)) * back_]; \
     } while (0)
 #define XB_COMMIT_W(DST)                                                                          \
     do {                                                                                          \
@@ -501,8 +512,8 @@ __global__ __launch_bounds__(256, 1) void conv_split_big_kernel(const ConvParams
         XB_FRAGS(KY, 1, fa1, fw1);                                                                \
         XB_TAP(fa0, fw0);                                                                         \
         XB_COMMIT_W(wts_next);                                                                    \
-        XB_COMMIT_ITEM(I0, patch_next);                                                           \
-        if ((I1) >= 0) XB_COMMIT_ITEM((I1) >= 0 ? (I1) : 0, patch_next);                          \
+        XB_COMMIT_ITEM(I0, patch_next, tl_next);                                                  \
+        if ((I1) >= 0) XB_COMMIT_ITEM((I1) >= 0 ? (I1) : 0, patch_next, tl_next);                 \
         XB_FRAGS(KY, 2, fa0, fw0);                                                                \
         XB_TAP(fa1, fw1);                                                                         \
         XB_LOAD_W(ph + 2 < nph ? ph + 2 : nph - 1);                                               \
@@ -515,13 +526,15 @@ __global__ __launch_bounds__(256, 1) void conv_split_big_kernel(const ConvParams
 
     const h8 k11 = {(_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f,
                     (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f, (_Float16)0x1p-11f};
-    const int nph = p.nchunk * 3;
+    const int nfull = p.nchunk - p.tail;                 // full 16-channel chunks; a folded 4-channel tail may follow
+    const int nph = nfull * 3 + p.tail;                  // weight slabs: three kernel rows per full chunk (+ the tail's)
+    const f32x4 *wtail = reinterpret_cast<const f32x4 *>(p.wtail) + n0;
     // prologue: chunk 0 and weight row 0 into LDS, chunk 1 and row 1 into registers
 #pragma unroll
     for (int i = 0; i < PM; ++i) XB_LOAD_ITEM(i);
     XB_LOAD_W(0);
 #pragma unroll
-    for (int i = 0; i < PM; ++i) XB_COMMIT_ITEM(i, patch0);
+    for (int i = 0; i < PM; ++i) XB_COMMIT_ITEM(i, patch0, false);
     XB_COMMIT_W(wts0);
     XB_ADVANCE();
 #pragma unroll
@@ -530,13 +543,42 @@ __global__ __launch_bounds__(256, 1) void conv_split_big_kernel(const ConvParams
     __syncthreads();
 
     int ph = 0;
-    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    for (int chunk = 0; chunk < nfull; ++chunk) {
         const _Float16 *patch = patch0 + (chunk & 1) * PBUF;
         _Float16 *patch_next = patch0 + ((chunk + 1) & 1) * PBUF;
+        const bool tl_next = p.tail && chunk + 1 == nfull;       // what this chunk's phases stage is the tail
         XB_ADVANCE();            // the registers this chunk's phases free are refilled with chunk + 2 (clamped to the last chunk)
         XB_PHASE(0, 0, 1);
         XB_PHASE(1, 2, 3);
         XB_PHASE(2, 4, -1);
+    }
+    if (p.tail) {
+        // The last source's 4 channels, taps folded into K: K16 step g covers taps 4g .. 4g+3 x 4 channels (k-half hh: taps 4g+2hh,
+        // 4g+2hh+1), three steps instead of nine taps of a chunk that would be 3/4 zeros.  Its records and its weight slab were
+        // staged by the last full chunk's phases.
+        const _Float16 *tp = patch0 + (nfull & 1) * PBUF;
+        const _Float16 *wts = wts0 + (ph & 1) * WROW;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int ta = 4 * g + 2 * hh, tb = ta + 1 < 9 ? ta + 1 : 8, tc = ta < 9 ? ta : 8;      // taps past the ninth have zero weights
+            const int oa = ((tc / 3) * PW + tc % 3) * 8, ob = ((tb / 3) * PW + tb % 3) * 8;
+            h8 fa[MT][2], fw[NT][2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const _Float16 *q = tp + ((wave * MT + m) * PW + row) * 8;
+                const h4 ha = *reinterpret_cast<const h4 *>(q + oa), ma = *reinterpret_cast<const h4 *>(q + oa + 4);
+                const h4 hb = *reinterpret_cast<const h4 *>(q + ob), mb = *reinterpret_cast<const h4 *>(q + ob + 4);
+                fa[m][0] = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+                fa[m][1] = __builtin_shufflevector(ma, mb, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            const _Float16 *wk = wts + g * 4 * BN * 8 + bbase;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                fw[n][0] = *reinterpret_cast<const h8 *>(wk + n * 256);
+                fw[n][1] = *reinterpret_cast<const h8 *>(wk + 2 * BN * 8 + n * 256);
+            }
+            XB_TAP(fa, fw);
+        }
     }
 #undef XB_ADVANCE
 #undef XB_LOAD_ITEM
@@ -641,12 +683,19 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
         // results; 128->128 at 1024^2: 841 -> 769 us, at 512^2: 221 -> 196; fewer tiles or chunks: its prologue does not pay)
         const long t16 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 16) * p.B;
         const bool fits31 = (size_t)p.H * p.W * 4 * 160 < ((size_t)1 << 31);      // 32-bit buffer offsets inside one image
-        if (p.ksplit == 1 && p.cout_pad % 128 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 128) >= 512 && p.nchunk >= 6 && fits31 &&
-            !(PIV_KNOB(1) & 262144))
-            return launch_xbig<4>(p, st);
-        if (p.ksplit == 1 && p.cout_pad % 64 == 0 && p.KH == 3 && p.KW == 3 && t16 * (p.cout_pad / 64) >= 512 && p.nchunk >= 6 && fits31 &&
+        // A folded tail (p.wtail) only exists for this kernel and sums in another order than the zero-padded tail chunk of the
+        // others: for layers that have one, the kernel is chosen from the per-image tile count (a pair's bits must not depend on
+        // its batch mates); layers without a tail give the same bits on every kernel and may follow the batch.
+        ConvParamsX pt = p;
+        const bool fold = p.wtail && !(PIV_KNOB(1) & 32);
+        pt.tail = fold ? 1 : 0;
+        const long t16b = fold ? (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 16) : t16;
+        if (p.ksplit == 1 && p.cout_pad % 128 == 0 && p.KH == 3 && p.KW == 3 && t16b * (p.cout_pad / 128) >= 512 &&
+            (p.nchunk >= 6 || (fold && p.nchunk >= 4)) && fits31 && !(PIV_KNOB(1) & 262144))
+            return launch_xbig<4>(pt, st);
+        if (p.ksplit == 1 && p.cout_pad % 64 == 0 && p.KH == 3 && p.KW == 3 && t16b * (p.cout_pad / 64) >= 512 && p.nchunk >= 6 && fits31 &&
             !(PIV_KNOB(1) & 131072))
-            return launch_xbig<2>(p, st);       // 128->64 at 1024^2: 476 -> 445 us
+            return launch_xbig<2>(pt, st);       // 128->64 at 1024^2: 476 -> 445 us
         // 128-channel tiles unless that leaves fewer than four workgroups per CU (tile shapes never change a result's bits)
         const long t128 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B * (p.cout_pad / 128);
         if (p.cout_pad % 128 == 0 && !wide && !tall && t128 >= 1024) return launch_x<3, 2, 4, 3, 6, 2>(p, st);
@@ -667,6 +716,31 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
     }
     if (wide) return launch_x<6, 2, 1, 5, 6, 2>(p, st);
     return tall ? launch_x<6, 2, 1, 5, 3, 2>(p, st) : launch_x<6, 2, 1, 3, 3, 2>(p, st);
+}
+
+static unsigned short f16_bits(float v);
+
+// The 4-lane tail chunk of a 3 x 3 layer with its taps folded into K (conv_split_big_kernel): [step g][piece][k-half][cout_pad][8],
+// element j of k-half kb = tap 4g + 2kb + (j >> 2), channel c_tail + (j & 3); same power-of-two scale as pack_conv_x.
+void pack_conv_x_tail(const float *w, int cout, int cin, int c_first, int c_real, float scale_inv, std::vector<unsigned short> &pk)
+{
+    const int cp = (cout + 31) / 32 * 32;
+    const double s = 1.0 / (double)scale_inv;
+    pk.assign((size_t)3 * 2 * 2 * cp * 8, 0);
+    for (int g = 0; g < 3; ++g)
+        for (int kb = 0; kb < 2; ++kb)
+            for (int j = 0; j < 8; ++j) {
+                const int t = 4 * g + 2 * kb + (j >> 2), c = j & 3;
+                if (t >= 9 || c >= c_real) continue;
+                for (int n = 0; n < cout; ++n) {
+                    const double bw = (double)w[((size_t)n * cin + c_first + c) * 9 + t] * s;
+                    const float bh = (float)(_Float16)(float)bw;
+                    const float bm = (float)(_Float16)(float)((bw - (double)bh) * 2048.0);
+                    const float piece[2] = {bh, bm * 0x1p-11f};
+                    for (int q = 0; q < 2; ++q)
+                        pk[((((size_t)g * 2 + q) * 2 + kb) * cp + n) * 8 + j] = f16_bits(piece[q]);
+                }
+            }
 }
 
 static unsigned short f16_bits(float v)

@@ -23,6 +23,7 @@ void pack_conv_h(const float *w, int cout, int cin, int taps, const int *creal, 
                  std::vector<unsigned short> &pk, int *nchunk_out);      // conv_f16.hip
 void pack_conv_x(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
                  std::vector<unsigned short> &pk, int *nchunk_out, float *out_scale);      // conv_split.hip
+void pack_conv_x_tail(const float *w, int cout, int cin, int c_first, int c_real, float scale_inv, std::vector<unsigned short> &pk);
 
 struct ConvW {
     float *wpk = nullptr, *bias = nullptr;
@@ -32,6 +33,7 @@ struct ConvW {
     void *wpk_x = nullptr;         // three-piece fp16 packing for conv_split.hip (fp32 by exact splitting); nullptr = unsupported geometry
     int nchunk_x = 0;
     float scale_x = 1.f;           // 2^-k undoing the weight scale of wpk_x
+    void *wtail_x = nullptr;       // 3 x 3 layers whose staged channels end in a 4-lane tail: that chunk with taps folded into K
 };
 
 struct LevelW {
@@ -172,6 +174,21 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         net->allocs.push_back(d);
         PIV_CHECK_HIP(hipMemcpy(d, px.data(), px.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         out->wpk_x = d;
+        // a 4-lane tail (the last source's cload = 4 mod 16): the same channels again, taps folded into K, for the 16-row kernel
+        const SegDef &ls = segs.back();
+        if (kh == 3 && kw == 3 && ls.cload % 16 == 4) {
+            int run = 0;
+            for (size_t si = 0; si + 1 < segs.size(); ++si) run += segs[si].creal;
+            const int first = (ls.coff >= 0 ? ls.coff : run) + ls.cload - 4;          // first weight channel of the tail lanes
+            const int real = std::max(0, std::min(4, ls.creal - (ls.cload - 4)));
+            std::vector<unsigned short> pt;
+            pack_conv_x_tail(w->data, cout, cin, first, real, out->scale_x, pt);
+            void *dt = nullptr;
+            PIV_CHECK_HIP(hipMalloc(&dt, pt.size() * sizeof(unsigned short)));
+            net->allocs.push_back(dt);
+            PIV_CHECK_HIP(hipMemcpy(dt, pt.data(), pt.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            out->wtail_x = dt;
+        }
     }
     return upload(net, bias, &out->bias);
 }
@@ -516,7 +533,7 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         int i = 0;
         for (auto &sg : segs) q.seg[i++] = sg;
         q.nseg = i;
-        q.wpk = cw.wpk_x; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
+        q.wpk = cw.wpk_x; q.wtail = cw.wtail_x; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
         q.cout_pad = cw.cout_pad; q.out_scale = cw.scale_x; q.terms = t_precision == 3 ? 3 : 6;
         q.B = B; q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
         q.KH = cw.KH; q.KW = cw.KW; q.S = S; q.padY = padY; q.padX = padX;
@@ -587,7 +604,7 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     memset(&q, 0, sizeof(q));
     q.seg[0] = ConvSeg{x, rup(c->cin, 4), x_stride};
     q.nseg = 1;
-    q.wpk = c->cw.wpk_x; q.bias = c->cw.bias; q.out = y; q.out_stride = y_stride;
+    q.wpk = c->cw.wpk_x; q.wtail = c->cw.wtail_x; q.bias = c->cw.bias; q.out = y; q.out_stride = y_stride;
     q.cout_store = std::min(rup(c->cw.cout, 4), y_stride);
     q.cout_pad = c->cw.cout_pad; q.out_scale = c->cw.scale_x; q.terms = terms;
     q.B = B; q.H = H; q.W = W; q.KH = c->cw.KH; q.KW = c->cw.KW; q.S = stride; q.padY = pad_y; q.padX = pad_x;
