@@ -340,7 +340,9 @@ static int launch_x(const ConvParamsX &p, hipStream_t st)
 //   * the operand fragments of tap kx+1 are read from LDS before the MFMAs of tap kx are issued (two register sets);
 //   * the phase body is straight-line code (no branches: out-of-image pixels and channel tails are buffer loads with an
 //     out-of-range offset, which return zero; past-the-end stages are clamped to the last chunk / row and land in a buffer nobody
-//     reads), so that the compiler can place the staging VALU / LDS / memory instructions between the MFMAs.
+//     reads), so that the compiler can place the staging VALU / LDS / memory instructions between the MFMAs;
+//   * a trailing 4-lane source (the 49-, 130-, 131-channel inputs) is not a 16-channel chunk that is 3/4 zeros but one extra phase
+//     with the taps folded into K (three K16 steps of 4 taps x 4 channels; p.tail / p.wtail).
 constexpr unsigned XOOB = 0x80000000u;
 
 template <int NT>
