@@ -98,13 +98,19 @@ size_t pivlfn_workspace_bytes(const pivlfn_net *net, int B, int H, int W);
 int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels,
                    int B, int H, int W, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Precision of the conv stacks inside pivlfn_forward: PIVLFN_PRECISION_F32 (default: fp32 operands on the fp32 matrix-core
- * instruction, the mode every fp32 parity statement and the headline benchmark refer to) or PIVLFN_PRECISION_F16 (BASELINE
- * config #5: operands rounded to fp16 while they are staged, fp32 accumulation, activations still fp32 in HBM; flows agree
- * with the fp32 mode to an end-point error stated in tests/test_gpu_f16.py).  Everything that is not a convolution
- * (correlation, warps, flow heads, regularisation tail) is fp32 in both modes. */
+/* Precision of the conv stacks inside pivlfn_forward.
+ * PIVLFN_PRECISION_F32 (the library's default, the mode every fp32 parity statement and the headline benchmark refer to):
+ * fp32 operands, fp32 products and fp32 accumulation on the fp32 matrix-core instruction v_mfma_f32_32x32x2_f32 (exact fma
+ * chains).  The 3 x 3 / stride 1 layers with an output grid of at least 32 x 32 per image are computed by Winograd's minimal
+ * filtering F(2x2, 3x3) (csrc/conv_wino.hip; the algorithm cuDNN / MIOpen choose for fp32 3 x 3 layers: 2.25 x fewer multiplies,
+ * all of them fp32 x fp32 on 24-bit operands; tests/test_gpu_wino.py measures the error against float64 next to the direct
+ * kernel's); every other layer by direct convolution.  PIVLFN_PRECISION_F32_DIRECT: direct convolution for every layer.
+ * PIVLFN_PRECISION_F16 (BASELINE config #5): operands rounded to fp16 while they are staged, fp32 accumulation, activations
+ * still fp32 in HBM; flows agree with the fp32 mode to an end-point error stated in tests/test_gpu_f16.py.
+ * Everything that is not a convolution (correlation, warps, flow heads, regularisation tail) is fp32 in all modes. */
 #define PIVLFN_PRECISION_F32 0
 #define PIVLFN_PRECISION_F16 1
+#define PIVLFN_PRECISION_F32_DIRECT 4
 /* PIVLFN_PRECISION_F32_SPLIT: fp32 results from the fp16 matrix cores.  Every fp32 operand is split exactly into three fp16
  * pieces (11 + 11 + 2 significand bits at scales 1, 2^-11, 2^-22) and each product is formed from six exact fp16 x fp16
  * products accumulated in fp32; what is dropped is below 2^-32 of a product, 256 x under the rounding of an fp32 fma
@@ -118,7 +124,8 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
  * a product carries a relative error of at most 2^-21 (typically 2^-23.5, about one fp32 ulp on each operand); measured against
  * float64 the layer outputs are as accurate as SPLIT's and more accurate than the fp32 instruction's (fewer roundings in the
  * accumulation), at half the matrix work.  Applies to the residual-free convolutions with an output grid of at least 64 x 64 per
- * image: stride 1 (4-row tiles and split-K on the small grids) and 3 x 3 stride 2.  The library's default. */
+ * image: stride 1 (4-row tiles and split-K on the small grids) and 3 x 3 stride 2.  Opt-in (not the default): the multiplicands
+ * are 22-23 bits wide, one fewer than fp32's. */
 #define PIVLFN_PRECISION_F32_SPLIT3 3
 int pivlfn_set_precision(pivlfn_net *net, int precision);
 
@@ -147,6 +154,11 @@ int pivlfn_conv2d_nhwc_f16(const pivlfn_conv *conv, const void *x, int x_stride,
  * PIVLFN_PRECISION_F32_SPLIT3 (terms = 3): fp32 x, fp32 y. */
 int pivlfn_conv2d_nhwc_split(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                              int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, int terms, void *stream);
+
+/* The same layer (3 x 3, stride 1, pad 1, no residual) on the Winograd F(2x2, 3x3) kernel PIVLFN_PRECISION_F32 uses: fp32 x,
+ * fp32 y, output grid = input grid. */
+int pivlfn_conv2d_nhwc_wino(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                            int B, int H, int W, int leaky, void *stream);
 
 /* The 32 -> 2 channel k x k flow head (conv_M.6 / conv_S.6) on its dedicated kernel: x [B,H,W,32], res4/out4 [B,H,W,4]. */
 int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W,

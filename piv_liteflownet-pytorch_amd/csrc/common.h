@@ -162,6 +162,19 @@ struct ConvParamsX {
 };
 int launch_conv_x(const ConvParamsX &p, hipStream_t st);
 bool conv_split_supports(int KH, int KW, int S, int cout_pad, int terms);
+// ---- 3x3 stride-1 layers by Winograd F(2x2, 3x3) on the fp32 matrix cores (conv_wino.hip): fp32 everywhere, K chunks of 8 channels ----
+struct ConvParamsW {
+    ConvSeg seg[3];
+    int nseg;
+    const float *wpk;   // Winograd-domain weights, [nchunk][cout_pad/32][4][4][64][4] (pack_conv_w)
+    const float *bias;  // [cout_pad]
+    float *out;         // NHWC fp32, channel offset applied
+    int out_stride, cout_store, cout_pad;
+    int B, H, W;        // output grid = input grid (3x3, stride 1, pad 1)
+    int nchunk, lrelu;
+};
+int launch_conv_w(const ConvParamsW &p, hipStream_t st);
+bool conv_wino_supports(int KH, int KW, int S, int padY, int padX);
 // 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device
 int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                      int k, hipStream_t st);

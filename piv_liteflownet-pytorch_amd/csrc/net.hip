@@ -24,6 +24,8 @@ void pack_conv_h(const float *w, int cout, int cin, int taps, const int *creal, 
 void pack_conv_x(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
                  std::vector<unsigned short> &pk, int *nchunk_out, float *out_scale);      // conv_split.hip
 void pack_conv_x_tail(const float *w, int cout, int cin, int c_first, int c_real, float scale_inv, std::vector<unsigned short> &pk);
+void pack_conv_w(const float *w, int cout, int cin, const int *creal, const int *cload, const int *coff, int nseg,
+                 std::vector<float> &pk, int *nchunk_out);      // conv_wino.hip
 
 struct ConvW {
     float *wpk = nullptr, *bias = nullptr;
@@ -34,6 +36,8 @@ struct ConvW {
     int nchunk_x = 0;
     float scale_x = 1.f;           // 2^-k undoing the weight scale of wpk_x
     void *wtail_x = nullptr;       // 3 x 3 layers whose staged channels end in a 4-lane tail: that chunk with taps folded into K
+    float *wpk_w = nullptr;        // 3 x 3 layers: Winograd-domain weights G g G^T in fragment order (conv_wino.hip)
+    int nchunk_w = 0;
 };
 
 struct LevelW {
@@ -63,7 +67,8 @@ struct pivlfn_net {
     int nstack = 3;                // hidden conv_M / conv_S layers: 3 = LiteFlowNet (src/models.py:154-163), 5 = LiteFlowNet2 (:487-500)
     int width[5] = {128, 64, 32, 0, 0};
     float mean[6];
-    int precision = 3;             // PIVLFN_PRECISION_*: 0 fp32 instruction, 1 fp16 multiplicands, 2 / 3 fp32 by operand splitting (default 3)
+    int precision = 0;             // PIVLFN_PRECISION_*: 0 fp32 instruction (default; 3x3 stride-1 layers by Winograd), 1 fp16 multiplicands,
+                                   // 2 / 3 fp32 by operand splitting, 4 fp32 instruction with direct convolution everywhere
     pivlfn::ConvW netc[10];
     pivlfn::ConvW ext[3];          // index by level (1,2)
     pivlfn::LevelW lv[7];
@@ -163,6 +168,14 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         net->allocs.push_back(d);
         PIV_CHECK_HIP(hipMemcpy(d, ph.data(), ph.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         out->wpk_h = d;
+    }
+    if (kh == 3 && kw == 3) {      // 3 x 3: the Winograd-domain packing (used by the stride-1 call sites)
+        std::vector<int> cr, cl, co;
+        for (auto &sg : segs) { cr.push_back(sg.creal); cl.push_back(sg.cload); co.push_back(sg.coff); }
+        std::vector<float> pw;
+        pack_conv_w(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w);
+        rc = upload(net, pw, &out->wpk_w);
+        if (rc) return rc;
     }
     if (conv_split_supports(kh, kw, 1, cp, 6)) {   // the split-operand packing of the same layer (fp32 on the fp16 matrix cores)
         std::vector<int> cr, cl, co;
@@ -542,6 +555,20 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         q.scratch_floats = KSPLIT_FLOATS * B;
         return launch_conv_x(q, st);
     }
+    // fp32 mode: the 3 x 3 / stride 1 layers by Winograd F(2x2, 3x3) on the fp32 matrix instruction (conv_wino.hip) from a
+    // 32 x 32 grid per image up; the bound is per image, never a function of the batch
+    if (t_precision == 0 && !res && cw.wpk_w && conv_wino_supports(cw.KH, cw.KW, S, padY, padX) &&
+        (long)Ho * Wo >= (PIV_KNOB(12) ? PIV_KNOB(12) : 32 * 32) && cout_store % 4 == 0) {
+        ConvParamsW q;
+        memset(&q, 0, sizeof(q));
+        int i = 0;
+        for (auto &sg : segs) q.seg[i++] = sg;
+        q.nseg = i;
+        q.wpk = cw.wpk_w; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
+        q.cout_pad = cw.cout_pad;
+        q.B = B; q.H = H; q.W = W; q.nchunk = cw.nchunk_w; q.lrelu = lrelu;
+        return launch_conv_w(q, st);
+    }
     ConvParams p;
     memset(&p, 0, sizeof(p));
     int i = 0;
@@ -561,7 +588,7 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
 
 int net_set_precision(pivlfn_net *net, int precision)
 {
-    PIV_REQUIRE(net && precision >= 0 && precision <= 3, "set_precision: 0 (fp32 instruction), 1 (fp16 multiplicands), 2 (fp32 by exact splitting) or 3 (three-term splitting) expected");
+    PIV_REQUIRE(net && precision >= 0 && precision <= 4, "set_precision: 0 (fp32 instruction), 1 (fp16 multiplicands), 2 (fp32 by exact splitting), 3 (three-term splitting) or 4 (fp32 instruction, direct convolution only) expected");
     net->precision = precision;
     return PIVLFN_OK;
 }
@@ -613,6 +640,25 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     q.nchunk = c->cw.nchunk_x; q.lrelu = leaky;
     q.scratch = c->scratch; q.scratch_floats = KSPLIT_FLOATS;
     return launch_conv_x(q, st);
+}
+
+// Standalone 3 x 3 / stride 1 / pad 1 layer on the Winograd kernel (tests, tools): fp32 in, fp32 out.
+int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, int B, int H, int W, int leaky,
+                   hipStream_t st)
+{
+    PIV_REQUIRE(c && x && y, "conv2d_wino: null argument");
+    PIV_REQUIRE(c->cw.wpk_w, "conv2d_wino: the layer is not 3 x 3 (k=%dx%d)", c->cw.KH, c->cw.KW);
+    PIV_REQUIRE(x_stride % 4 == 0 && x_stride >= rup(c->cin, 4), "conv2d_wino: x_stride=%d must be a multiple of 4 and >= %d", x_stride, rup(c->cin, 4));
+    PIV_REQUIRE(y_stride % 4 == 0 && y_stride >= c->cw.cout, "conv2d_wino: y_stride=%d must be a multiple of 4 and >= cout=%d", y_stride, c->cw.cout);
+    ConvParamsW q;
+    memset(&q, 0, sizeof(q));
+    q.seg[0] = ConvSeg{x, rup(c->cin, 4), x_stride};
+    q.nseg = 1;
+    q.wpk = c->cw.wpk_w; q.bias = c->cw.bias; q.out = y; q.out_stride = y_stride;
+    q.cout_store = std::min(rup(c->cw.cout, 4), y_stride);
+    q.cout_pad = c->cw.cout_pad;
+    q.B = B; q.H = H; q.W = W; q.nchunk = c->cw.nchunk_w; q.lrelu = leaky;
+    return launch_conv_w(q, st);
 }
 
 int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels, int B, int H, int W,

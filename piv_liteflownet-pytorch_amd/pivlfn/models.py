@@ -84,26 +84,27 @@ class LiteFlowNet(torch.nn.Module):
         self._handle = None
         self._handle_key = None
         self._ws = None
-        self._precision = "fp32_split3"
+        self._precision = "fp32"
 
     # -- precision of the conv stacks ---------------------------------------------------------------------
-    _PRECISIONS = {"fp32": 0, "fp16": 1, "fp32_split": 2, "fp32_split3": 3}
+    _PRECISIONS = {"fp32": 0, "fp16": 1, "fp32_split": 2, "fp32_split3": 3, "fp32_direct": 4}
 
     @property
     def precision(self) -> str:
         """How the large convolutions multiply (everything else -- correlation, warps, heads, small levels -- is fp32 throughout):
-        'fp32_split3' (default) fp32 operands as two fp16 pieces each, the three leading partial products on the fp16 matrix
-                      cores, fp32 accumulation: products good to 2^-21 (typically 2^-23.5), layer outputs as close to float64 as
-                      'fp32_split' and closer than 'fp32' (csrc/conv_split.hip, tests/test_gpu_split.py);
-        'fp32_split'  three pieces, six partial products: products exact to 2^-32;
-        'fp32'        the fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32), 1/16 of the fp16 instruction's rate;
+        'fp32'        (default) the fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32: fp32 operands, exact fp32 fma chains);
+                      the 3x3 stride-1 layers by Winograd F(2x2, 3x3) in fp32 (csrc/conv_wino.hip), the rest by direct convolution;
+        'fp32_direct' the same instruction, direct convolution for every layer (2.25 x the multiplies of 'fp32' in the 3x3 layers);
+        'fp32_split'  fp32 operands as three fp16 pieces each (all 24 bits), six partial products on the fp16 matrix cores, fp32
+                      accumulation: products exact to 2^-32 (csrc/conv_split.hip); inputs of those layers must stay below 65504;
+        'fp32_split3' two pieces, three partial products: 22-23 operand bits, products good to 2^-21 -- narrower than fp32, opt-in;
         'fp16'        operands rounded to fp16 (BASELINE config #5): reduced precision, its own tolerance."""
         return self._precision
 
     @precision.setter
     def precision(self, value: str) -> None:
         if value not in self._PRECISIONS:
-            raise ValueError("precision must be 'fp32', 'fp32_split', 'fp32_split3' or 'fp16'")
+            raise ValueError("precision must be 'fp32', 'fp32_direct', 'fp32_split', 'fp32_split3' or 'fp16'")
         self._precision = value
         if self.__dict__.get("_handle") is not None:
             _lib.check(_lib.load().pivlfn_set_precision(self._handle, self._PRECISIONS[value]), "set_precision")

@@ -159,9 +159,10 @@ def _check(got, want, what):
     assert err.mean() <= E2E_MEAN * scale, f"{what}: mean-abs {err.mean():.3e}"
 
 
-def test_default_precision_is_the_three_term_split(dev):
+def test_split_modes_are_opt_in(dev):
+    """The default is the fp32 instruction ('fp32'); the split modes have to be asked for."""
     net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
-    assert net.precision == "fp32_split3"
+    assert net.precision == "fp32"
 
 
 @pytest.mark.parametrize("mode", ["fp32_split3", "fp32_split"])
@@ -197,11 +198,11 @@ def test_golden_case_small_grids(gold, dev):
     i2 = torch.from_numpy(np.stack([synth.to_input(a) for a in g[f"{tag}_img2"]])).to(dev)
     net = pivlfn.Network(model="piv", params=synth.generate_weights("piv", 0)).to(dev).eval()
     outs = {}
-    for mode in ("fp32", "fp32_split", "fp32_split3"):
+    for mode in ("fp32_direct", "fp32_split", "fp32_split3"):
         net.precision = mode
         outs[mode] = net(i1, i2).cpu().numpy()
-    assert np.array_equal(outs["fp32"], outs["fp32_split"]) and not np.array_equal(outs["fp32"], outs["fp32_split3"])
-    _check(outs["fp32"], g[f"{tag}_flow"], f"{tag} fp32 instruction vs reference flows")
+    assert np.array_equal(outs["fp32_direct"], outs["fp32_split"]) and not np.array_equal(outs["fp32_direct"], outs["fp32_split3"])
+    _check(outs["fp32_direct"], g[f"{tag}_flow"], f"{tag} fp32 instruction (direct) vs reference flows")
     _check(outs["fp32_split3"], g[f"{tag}_flow"], f"{tag} three-term split vs reference flows")
 
 
@@ -213,6 +214,7 @@ def test_three_term_mode_small_levels_split_k(size, dev):
     a, b = synth.particle_batch(3, H * 2, W * 2, seed=31 + H)
     i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    net.precision = "fp32_split3"
     full = net(i1, i2)
     for k in range(3):
         assert torch.equal(net(i1[k:k + 1], i2[k:k + 1])[0], full[k])

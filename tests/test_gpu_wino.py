@@ -1,0 +1,128 @@
+"""GPU: the Winograd F(2x2, 3x3) kernel of the default fp32 mode (csrc/conv_wino.hip) against a float64 convolution of the same
+fp32 data, next to the direct kernel on the same layer.  Replaces the 3x3 / stride 1 torch.nn.Conv2d call sites of
+/root/reference/src/models.py:77-101, 154-160, 197-204, 236-250.  Tolerance (fp32): max-abs <= 1e-5 * max|out| per layer, the
+bar the direct kernel is held to in test_gpu_conv.py (2e-5); the measured errors are printed."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pivlfn import _lib
+from test_gpu_conv import Conv, run as run_direct
+
+pytestmark = pytest.mark.gpu
+
+
+def run_wino(conv, x_nchw, leaky, dev, x_lanes=None, y_lanes=None):
+    B, C, H, W = x_nchw.shape
+    co = conv.w.shape[0]
+    xs = x_lanes or -(-C // 4) * 4
+    x = torch.zeros(B, H, W, xs)
+    x[..., :C] = x_nchw.permute(0, 2, 3, 1)
+    x = x.to(dev)
+    ys = y_lanes or -(-co // 4) * 4
+    y = torch.full((B, H, W, ys), float("nan"), device=dev)
+    _lib.check(_lib.load().pivlfn_conv2d_nhwc_wino(conv.h, x.data_ptr(), xs, y.data_ptr(), ys, B, H, W, int(leaky),
+                                                   torch.cuda.current_stream(dev).cuda_stream), "conv2d_wino")
+    y = y.cpu()
+    cs = min(-(-co // 4) * 4, ys)
+    assert torch.all(y[..., co:cs] == 0)            # padding lanes are exact zeros
+    if ys > cs:
+        assert torch.isnan(y[..., cs:]).all()       # lanes beyond the stored ones are never touched
+    return y[..., :co].permute(0, 3, 1, 2).contiguous()
+
+
+CASES = [
+    # cout, cin, H, W, B
+    (128, 128, 32, 48, 1),       # conv_R.2
+    (128, 49, 32, 64, 1),        # conv_M.0: 6 chunks + a 4-lane tail (one real channel in it)
+    (64, 128, 19, 35, 2),        # odd sizes: half tiles at the right and bottom edges
+    (32, 64, 16, 16, 3),
+    (32, 32, 64, 64, 1),         # NetC.conv2.x
+    (96, 96, 24, 40, 1),         # NetC.conv4.2: three N blocks
+    (64, 64, 1, 1, 1),           # a single pixel
+    (32, 36, 5, 3, 1),           # 4-lane tail, image smaller than a tile
+    (128, 386, 8, 8, 1),         # conv_S.0 level-6 width
+    (9, 32, 8, 24, 2),           # cout not a multiple of 4: lanes 9..11 zero
+    (128, 128, 130, 70, 1),      # several workgroups in both directions, ragged
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wino_matches_float64_conv(case, dev):
+    co, ci, H, W, B = case
+    g = torch.Generator().manual_seed(co * 1000 + ci + H)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    x = torch.randn(B, ci, H, W, generator=g)
+    conv = Conv(w, b)
+    for leaky in (False, True):
+        want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        if leaky:
+            want = F.leaky_relu(want, 0.1)
+        got = run_wino(conv, x, leaky, dev)
+        err = (got.double() - want).abs().max().item()
+        assert err < 1e-5 * max(1.0, want.abs().max().item()), (case, err)
+
+
+def test_wino_error_beside_the_direct_kernel(dev):
+    """A cancellation-heavy layer -- post-LeakyReLU-like activations with a positive mean (|N(0,1)| + 10) against zero-mean
+    weights, error normalised by the RMS of the output (not its maximum): Winograd in fp32 stays within 2x the direct fp32
+    kernel's error against float64."""
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(128, 128, 3, 3, generator=g) / (128 * 9) ** 0.5
+    b = torch.zeros(128)
+    x = torch.randn(1, 128, 64, 96, generator=g).abs() + 10.0
+    conv = Conv(w, b)
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    rms = want.pow(2).mean().sqrt().item()
+    ew = (run_wino(conv, x, False, dev).double() - want).abs()
+    ed = (run_direct(conv, x, 1, (1, 1), False, dev).double() - want).abs()
+    print(f"128->128 3x3, x = |N|+10: rms(out) {rms:.3f}; Winograd max {ew.max().item() / rms:.2e} mean {ew.mean().item() / rms:.2e}; "
+          f"direct max {ed.max().item() / rms:.2e} mean {ed.mean().item() / rms:.2e} (of rms)")
+    assert ew.mean().item() <= 2.0 * ed.mean().item() + 1e-9
+    assert ew.max().item() <= 1e-5 * rms * 10        # absolute bar: 1e-4 of the output's rms on a layer whose inputs are 10x its outputs
+
+
+def test_wino_wide_lanes_and_batch_invariance(dev):
+    """Input living in a wider tensor, output into a wider tensor; a sample's bits do not depend on its batch mates or on the tile
+    shape the launch picks (8-row blocks for small launches, 16-row blocks for large ones)."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17
+    b = torch.randn(64, generator=g)
+    conv = Conv(w, b)
+    x = torch.randn(40, 32, 64, 64, generator=g)          # 40 x 4 x 4 x 2 = 1280 16-row blocks -> MB = 2
+    full = run_wino(conv, x, True, dev, x_lanes=40, y_lanes=72)
+    one = run_wino(conv, x[7:8], True, dev, x_lanes=40, y_lanes=72)      # 32 blocks -> MB = 1
+    assert torch.equal(one[0], full[7])
+    want = F.leaky_relu(F.conv2d(x[7:8].double(), w.double(), b.double(), padding=1), 0.1)
+    assert (one.double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
+
+
+def test_wino_refuses_what_it_does_not_cover(dev):
+    g = torch.Generator().manual_seed(1)
+    conv = Conv(torch.randn(32, 32, 1, 1, generator=g), torch.zeros(32))
+    x = torch.zeros(1, 8, 8, 32, device=dev)
+    y = torch.zeros(1, 8, 8, 32, device=dev)
+    rc = _lib.load().pivlfn_conv2d_nhwc_wino(conv.h, x.data_ptr(), 32, y.data_ptr(), 32, 1, 8, 8, 0, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc != 0 and b"3 x 3" in _lib.load().pivlfn_last_error()
+
+
+def test_default_mode_is_fp32_with_winograd(dev):
+    """The network's default precision is 'fp32'; it differs from 'fp32_direct' only in summation order (both meet the oracle
+    tolerance in test_gpu_net.py), and both reproduce themselves bit for bit."""
+    import pivlfn
+    from pivlfn import synth
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    assert net.precision == "fp32"
+    a, b, _ = synth.particle_pair(256, 256, 77)
+    x1, x2 = torch.from_numpy(synth.to_input(a))[None].to(dev), torch.from_numpy(synth.to_input(b))[None].to(dev)
+    fw = net(x1, x2)
+    net.precision = "fp32_direct"
+    fd = net(x1, x2)
+    net.precision = "fp32"
+    assert torch.equal(net(x1, x2), fw)
+    assert not torch.equal(fw, fd)
+    d = (fw - fd).abs().max().item()
+    print(f"piv 256x256: max |flow(fp32, Winograd) - flow(fp32_direct)| = {d:.2e} px at max |flow| {fd.abs().max().item():.2f}")
+    assert d < 1e-4 * max(1.0, fd.abs().max().item())

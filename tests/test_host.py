@@ -167,10 +167,10 @@ def test_precision_property_without_a_gpu():
     """`Network.precision` is host state until the weights are uploaded: default, accepted names, refusal of anything else."""
     import pivlfn
     net = pivlfn.Network(model="piv")
-    assert net.precision == "fp32_split3"
-    for mode in ("fp32", "fp32_split", "fp16", "fp32_split3"):
+    assert net.precision == "fp32"
+    for mode in ("fp32_direct", "fp32_split", "fp16", "fp32_split3", "fp32"):
         net.precision = mode
         assert net.precision == mode
     with pytest.raises(ValueError):
         net.precision = "bf16"
-    assert net.precision == "fp32_split3"
+    assert net.precision == "fp32"

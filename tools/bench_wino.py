@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the 3x3 stride-1 layers of a 1024x1024 PIV forward: Winograd F(2x2,3x3) kernel (conv_wino.hip) beside the
+direct fp32 kernel (conv_mfma.hip), both on v_mfma_f32_32x32x2_f32, interleaved rounds in one process (production library).
+
+  python tools/bench_wino.py [--size 1024] [--levels 1,2] [--rounds 5] [--layers 128x128,128x64,...]
+TFLOP/s are those of the DIRECT algorithm's multiply count (2 * 9 * Cin * Cout per pixel) for both, so the ratio is the speed-up.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "piv_liteflownet-pytorch_amd"))
+from pivlfn import _lib  # noqa: E402
+
+LAYERS = [(49, 128), (128, 64), (64, 32), (130, 128), (131, 128), (128, 128), (64, 64), (32, 32)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--levels", default="1,2")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--n", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--layers", default="")
+    a = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    layers = [tuple(int(v) for v in s.split("x")) for s in a.layers.split(",")] if a.layers else LAYERS
+    for L in [int(x) for x in a.levels.split(",")]:
+        n = a.size >> (L - 1)
+        for ci, co in layers:
+            g = torch.Generator().manual_seed(ci * 7 + co)
+            w = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).contiguous()
+            b = torch.randn(co, generator=g).contiguous()
+            h = ctypes.c_void_p()
+            _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(h)), "create")
+            xs = -(-ci // 4) * 4
+            x = torch.randn(a.batch, n, n, xs, device=dev)
+            y = {k: torch.empty(a.batch, n, n, co, device=dev) for k in ("direct", "wino")}
+
+            def direct():
+                _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), xs, y["direct"].data_ptr(), co, None, 0, a.batch, n, n, 1, 1, 1, 1, st), "direct")
+
+            def wino():
+                _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y["wino"].data_ptr(), co, a.batch, n, n, 1, st), "wino")
+            fns = {"direct": direct, "wino": wino}
+            times = {k: [] for k in fns}
+            for k in fns:
+                fns[k]()
+            for rnd in range(a.rounds):
+                for k in (list(fns) if rnd % 2 == 0 else list(fns)[::-1]):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    fns[k]()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(a.n):
+                        fns[k]()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    times[k].append(e0.elapsed_time(e1) / a.n * 1e3)
+            flop = 2.0 * 9 * ci * co * n * n * a.batch
+            d = (y["wino"] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
+            td, tw = min(times["direct"]), min(times["wino"])
+            md, mw = sorted(times["direct"])[len(times["direct"]) // 2], sorted(times["wino"])[len(times["wino"]) // 2]
+            print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: direct min {td:8.1f} med {md:8.1f} us ({flop / td / 1e6:6.1f} TF)   "
+                  f"wino min {tw:8.1f} med {mw:8.1f} us ({flop / tw / 1e6:6.1f} TF-equiv, {flop / 2.25 / tw / 1e6:6.1f} TF executed)   "
+                  f"x{td / tw:4.2f}   rel diff {d:.1e}", flush=True)
+            lib.pivlfn_conv_destroy(h)
+
+
+if __name__ == "__main__":
+    main()
