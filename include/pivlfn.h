@@ -101,7 +101,7 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
 /* Precision of the conv stacks inside pivlfn_forward.
  * PIVLFN_PRECISION_F32 (the library's default, the mode every fp32 parity statement and the headline benchmark refer to):
  * fp32 operands, fp32 products and fp32 accumulation on the fp32 matrix-core instruction v_mfma_f32_32x32x2_f32 (exact fma
- * chains).  The 3 x 3 / stride 1 layers with an output grid of at least 32 x 32 per image are computed by Winograd's minimal
+ * chains).  The 3 x 3 / stride 1 layers with an output grid of at least 64 x 64 per image are computed by Winograd's minimal
  * filtering F(2x2, 3x3) (csrc/conv_wino.hip; the algorithm cuDNN / MIOpen choose for fp32 3 x 3 layers: 2.25 x fewer multiplies,
  * all of them fp32 x fp32 on 24-bit operands; tests/test_gpu_wino.py measures the error against float64 next to the direct
  * kernel's); every other layer by direct convolution.  PIVLFN_PRECISION_F32_DIRECT: direct convolution for every layer.

@@ -15,7 +15,8 @@
 //   * per plane a 32 x 32 x K matrix product  D[cout][tile] += U[cout][cin] V[cin][tile]  (A = weights, B = transformed
 //     activations): the B fragment comes straight out of the lane's transform registers, the A fragment straight from
 //     global memory (packed at load time in fragment order: one contiguous 1 KB per wave-load, L2-resident) -- the weights
-//     never touch LDS, and LDS holds only the raw 8-channel input patch (double-buffered, one barrier per K chunk);
+//     never touch LDS, and LDS holds only the raw 8-channel input patch (double-buffered, one barrier per K chunk;
+//     stored de-interleaved so the stride-2 operand reads are conflict-free, see WPIXQ below);
 //   * epilogue: the column half of A^T M A in registers, the row half across the four waves through LDS (which is idle by
 //     then), bias / LeakyReLU, 16-byte NHWC stores.
 // Summation order per output value: chunks ascending, k = {j, 4+j} inside a chunk, then planes (fixed order): independent
@@ -30,24 +31,40 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int WPW = 18;      // patch width in pixels: 8 tiles x 2 + 2
-constexpr int WPIX = 8;      // floats per staged pixel = one K chunk
+// LDS image of one chunk's patch.  Every operand read is one 16-byte quad per lane at pixel (2 ty + r, 2 tx + c) of the lane's
+// tile (ty, tx): a stride of two pixels in both directions, which in a plain row-major image leaves only even 16-byte slots
+// (at least a two-way bank conflict; measured 65 % of all LDS cycles with a 32-byte pixel pitch).  The image is therefore stored
+// de-interleaved -- even columns then odd columns inside a row, even rows then odd rows -- so tiles are unit-stride in both
+// directions, with a pixel pitch of 3 quads (odd) and a row pitch of 8 quads (mod 16): the 16 lanes of every ds_read_b128 group
+// ({0-3,12-15,20-27}, ... = tile rows {0,3} x columns 0-3 and rows {1,2} x columns 4-7, or the complement) land on 16 distinct slots.
+constexpr int WPIXQ = 3;                       // 16-byte quads per staged pixel: 8 channels of the K chunk + 4 floats of padding
+constexpr int WROWQ = 56;                      // quads per patch row: 18 x 3 = 54, padded to 896 bytes = 8 quads mod 16
+// (all LDS offsets are kept in quads and applied to an f32x4 pointer, so every access is provably 16-byte aligned: with float
+// offsets the compiler splits the 16-byte reads and writes into ds_read2_b32 / ds_write2_b32 pairs)
 constexpr unsigned WOOB = 0x80000000u;
 
-template <int MB>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParamsW p)
+// MB = 32-tile blocks per wave (the workgroup covers 8 x 4 MB tiles = 16 x 8 MB pixels), NBW = 32-channel output blocks per wave
+// (the workgroup covers 32 NBW channels).  A transformed operand V feeds NBW MFMAs and a weight fragment MB MFMAs; on this chip
+// the fp32 MFMA and the fp32 vector instructions share the SIMD's fp32 datapath (tools/micro/mfma_valu_mix.hip: every vector
+// instruction beside v_mfma_f32_32x32x2_f32 costs the matrix work its 4 issue cycles), so the transform's two additions per V
+// are paid in matrix-pipe time and NBW is what amortises them.  4 MB NBW accumulators of 16 registers: up to 8 (128 registers)
+// two workgroups share a CU, 16 take the whole register file of one.
+template <int MB, int NBW>
+__global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel(const ConvParamsW p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TY = 4 * MB;                  // tile rows of the workgroup
     constexpr int PH = 2 * TY + 2;
     constexpr int NSLOT = PH * WPW * 2;         // 16-byte slots of one chunk's patch
     constexpr int PS = (NSLOT + 255) / 256;
-    constexpr int PBUF = (PH * WPW + 1) * WPIX; // floats per patch buffer (+ one spare record)
+    constexpr int PBUF = PH * WROWQ + WPIXQ;     // quads per patch buffer (+ one spare record)
 
-    const int NB = p.cout_pad >> 5;
+    const int NB = p.cout_pad >> 5;             // 32-channel blocks of the layer
+    const int NG = NB / NBW;                    // channel groups = workgroups per spatial tile
     const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 2 * TY - 1) / (2 * TY);
-    int t = xcd_remap(blockIdx.x, gridDim.x);   // the N blocks of a spatial tile run back to back on one XCD: its patch is fetched once into that L2
-    const int nb = t % NB;
-    t /= NB;
+    int t = xcd_remap(blockIdx.x, gridDim.x);   // the channel groups of a spatial tile run back to back on one XCD: its patch is fetched once into that L2
+    const int nb0 = (t % NG) * NBW;
+    t /= NG;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
@@ -74,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParamsW p)
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool in = idx < NSLOT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         ppix[s] = in ? (unsigned)(iy * p.W + ix) : WOOB;
-        plds[s] = (idx < NSLOT ? pix : PH * WPW) * WPIX + q4;
+        plds[s] = (idx < NSLOT ? ((py >> 1) + (py & 1) * (PH / 2)) * WROWQ + ((px >> 1) + (px & 1) * 9) * WPIXQ : PH * WROWQ) + (tid & 1);
     }
     // plane row i = wave: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
@@ -84,128 +101,191 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParamsW p)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int tyl = mb * 4 + (n >> 3), txl = n & 7;
-        abase[mb] = ((2 * tyl + ra) * WPW + 2 * txl) * WPIX + 4 * g;
-        bbase[mb] = ((2 * tyl + rb) * WPW + 2 * txl) * WPIX + 4 * g;
+        abase[mb] = (tyl + (ra >> 1) + (ra & 1) * (PH / 2)) * WROWQ + txl * WPIXQ + g;      // patch pixel (2 tyl + ra, 2 txl), in quads
+        bbase[mb] = (tyl + (rb >> 1) + (rb & 1) * (PH / 2)) * WROWQ + txl * WPIXQ + g;
     }
 
-    f32x16 acc[4][MB];
+    f32x16 acc[4][MB][NBW];
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[jp][mb][r] = 0.f;
+            for (int nw = 0; nw < NBW; ++nw)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jp][mb][nw][r] = 0.f;
 
-    // weights of (chunk, nb, wave): 4 planes x 64 lanes x 4 floats, contiguous
-    const float *wlane = p.wpk + ((size_t)nb * 4 + wave) * 1024 + lane * 4;
+    // weights of (chunk, nb, wave): 4 planes x 64 lanes x 4 floats, contiguous; the wave's NBW blocks are 4096 floats apart
+    const float *wbase = p.wpk + ((size_t)nb0 * 4 + wave) * 1024;
     const size_t wchunk = (size_t)NB * 4 * 1024;
 
-    int seg = 0, c0 = 0, lchunk = 0;
-    int scl = p.seg[0].cload, sst4 = p.seg[0].stride * 4;
+    // per-source descriptors and strides, built once (scalar registers); `seg`, `c0`, `lchunk` = the chunk whose patch is loaded next
     const size_t img_px = (size_t)p.H * p.W;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[0].ptr + (size_t)b * img_px * p.seg[0].stride), 0,
-                                                                    (unsigned)(((img_px - 1) * p.seg[0].stride + p.seg[0].cload) * 4), 0x00020000);
-    f32x4 pr[PS], wn[4], wc[4];
-
-#define WINO_LOAD()                                                                               \
-    do {                                                                                          \
-        const unsigned coff_ = (unsigned)(c0 + q4) * 4u;                                          \
-        const bool qok_ = c0 + q4 < scl;                                                          \
-        _Pragma("unroll") for (int s = 0; s < PS; ++s) {                                          \
-            const unsigned o_ = (ppix[s] != WOOB && qok_) ? ppix[s] * (unsigned)sst4 + coff_ : WOOB; \
-            pr[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o_, 0, 0)); \
-        }                                                                                         \
-        const float *w_ = wlane + (size_t)lchunk * wchunk;                                        \
-        _Pragma("unroll") for (int jp = 0; jp < 4; ++jp) wn[jp] = *reinterpret_cast<const f32x4 *>(w_ + jp * 256); \
-    } while (0)
-#define WINO_COMMIT(BUF)                                                                          \
-    do {                                                                                          \
-        _Pragma("unroll") for (int s = 0; s < PS; ++s) *reinterpret_cast<f32x4 *>(smem + (BUF)*PBUF + plds[s]) = pr[s]; \
-    } while (0)
-
-    WINO_LOAD();
-    WINO_COMMIT(0);
-    __syncthreads();
-    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    __amdgpu_buffer_rsrc_t rsv[3];
+    int sclv[3], sst4v[3];
 #pragma unroll
-        for (int jp = 0; jp < 4; ++jp) wc[jp] = wn[jp];
-        // the next chunk's patch and weights go in flight before this chunk's matrix work; past the end the last chunk is
-        // fetched again (into the buffer nobody reads any more), which keeps the body free of branches around loads
-        if (lchunk + 1 < p.nchunk) {
-            ++lchunk;
-            c0 += 8;
-            if (c0 >= scl) {
-                ++seg;
-                c0 = 0;
-                scl = p.seg[seg].cload; sst4 = p.seg[seg].stride * 4;
-                rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + (size_t)b * img_px * p.seg[seg].stride), 0,
-                                                       (unsigned)(((img_px - 1) * p.seg[seg].stride + p.seg[seg].cload) * 4), 0x00020000);
-            }
-        }
-        WINO_LOAD();
-        __builtin_amdgcn_sched_barrier(0);      // the loads stay in front of the matrix work (the scheduler would sink them to their first use)
-        const float *buf = smem + (chunk & 1) * PBUF;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            f32x4 tt[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 da = *reinterpret_cast<const f32x4 *>(buf + abase[mb] + c * WPIX);
-                const f32x4 db = *reinterpret_cast<const f32x4 *>(buf + bbase[mb] + c * WPIX);
-                tt[c] = da + sb * db;
-            }
-            f32x4 v[4];
-            v[0] = tt[0] - tt[2];
-            v[1] = tt[1] + tt[2];
-            v[2] = tt[2] - tt[1];
-            v[3] = tt[1] - tt[3];
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[jp][mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[jp][j], v[jp][j], acc[jp][mb], 0, 0, 0);
-        }
-        WINO_COMMIT((chunk + 1) & 1);
-        __syncthreads();
+    for (int s = 0; s < 3; ++s) {
+        const int ss = s < p.nseg ? s : 0;
+        sclv[s] = p.seg[ss].cload;
+        sst4v[s] = p.seg[ss].stride * 4;
+        rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[ss].ptr + (size_t)b * img_px * p.seg[ss].stride), 0,
+                                                   (unsigned)(((img_px - 1) * p.seg[ss].stride + p.seg[ss].cload) * 4), 0x00020000);
     }
-#undef WINO_LOAD
-#undef WINO_COMMIT
+    int seg = 0, c0 = 0, lchunk = 0;
+    unsigned pvo[PS];             // byte offset of the slot's pixel record (+ its quad) inside the current source, WOOB = none
+#pragma unroll
+    for (int s = 0; s < PS; ++s) pvo[s] = ppix[s] != WOOB ? ppix[s] * (unsigned)sst4v[0] + (unsigned)q4 * 4u : WOOB;
+    f32x4 pr[PS], wA[NBW][4], wB[NBW][4], vA[4], vB[4];
 
-    // ---- output transform.  acc[jp][mb][4 rg + e] = M[(wave, jp)][cout 8 rg + 4 g + e][tile n of block mb]
+// patch of chunk `lchunk` -> pr (voffset = the slot's record, soffset = the chunk's channel offset), then advance to the next chunk;
+// past the end the last chunk is fetched again (into a buffer nobody reads any more): the loop body has no branch around a load
+#define WINO_LOADP()                                                                              \
+    do {                                                                                          \
+        const int scl_ = seg == 0 ? sclv[0] : (seg == 1 ? sclv[1] : sclv[2]);                     \
+        const __amdgpu_buffer_rsrc_t rs_ = seg == 0 ? rsv[0] : (seg == 1 ? rsv[1] : rsv[2]);      \
+        const bool qok_ = c0 + q4 < scl_;                                                         \
+        _Pragma("unroll") for (int s = 0; s < PS; ++s)                                            \
+            pr[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? pvo[s] : WOOB), c0 * 4, 0)); \
+        if (lchunk + 1 < p.nchunk) {                                                              \
+            ++lchunk;                                                                             \
+            c0 += 8;                                                                              \
+            if (c0 >= scl_) {                                                                     \
+                ++seg;                                                                            \
+                c0 = 0;                                                                           \
+                const int sst4_ = seg == 1 ? sst4v[1] : sst4v[2];                                 \
+                _Pragma("unroll") for (int s = 0; s < PS; ++s)                                    \
+                    pvo[s] = ppix[s] != WOOB ? ppix[s] * (unsigned)sst4_ + (unsigned)q4 * 4u : WOOB; \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+#define WINO_LOADW(WN, CH)                                                                        \
+    do {                                                                                          \
+        const float *w_ = wbase + (size_t)(CH)*wchunk;                                            \
+        _Pragma("unroll") for (int nw = 0; nw < NBW; ++nw)                                        \
+            _Pragma("unroll") for (int jp = 0; jp < 4; ++jp)                                      \
+                WN[nw][jp] = *reinterpret_cast<const f32x4 *>(w_ + nw * 4096 + jp * 256 + lane * 4); \
+    } while (0)
+#define WINO_COMMIT(BOFF)                                                                         \
+    do {                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < PS; ++s) smem4[(BOFF) + plds[s]] = pr[s];          \
+    } while (0)
+// the lane's 8 operand quads of block MB_ (rows ra, rb x columns 0..3 of its tile's patch) from the patch image at quad offset BOFF
+#define WINO_READ(RAW, BOFF, MB_)                                                                 \
+    do {                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                           \
+            RAW[c] = smem4[(BOFF) + abase[MB_] + ((c >> 1) + (c & 1) * 9) * WPIXQ];               \
+            RAW[4 + c] = smem4[(BOFF) + bbase[MB_] + ((c >> 1) + (c & 1) * 9) * WPIXQ];           \
+        }                                                                                         \
+    } while (0)
+// V = (B^T d B)[wave][0..3]
+#define WINO_XFORM(V, RAW)                                                                        \
+    do {                                                                                          \
+        f32x4 tt_[4];                                                                             \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) tt_[c] = RAW[c] + sb * RAW[4 + c];          \
+        V[0] = tt_[0] - tt_[2];                                                                   \
+        V[1] = tt_[1] + tt_[2];                                                                   \
+        V[2] = tt_[2] - tt_[1];                                                                   \
+        V[3] = tt_[1] - tt_[3];                                                                   \
+    } while (0)
+#define WINO_MFMA(V, WC, MB_)                                                                     \
+    do {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            _Pragma("unroll") for (int jp = 0; jp < 4; ++jp)                                      \
+                _Pragma("unroll") for (int nw = 0; nw < NBW; ++nw)                                \
+                    acc[jp][MB_][nw] = __builtin_amdgcn_mfma_f32_32x32x2f32(WC[nw][jp][j], V[jp][j], acc[jp][MB_][nw], 0, 0, 0); \
+    } while (0)
+// One chunk: multiply chunk CH with (WC, VC); put chunk CH + 1's weights (-> WN) and chunk CH + 2's patch (-> pr -> LDS) in flight;
+// compute the first block's transform of chunk CH + 1 (-> VN) under the matrix work.
+#define WINO_STEP(WC, VC, WN, VN, CH)                                                             \
+    do {                                                                                          \
+        WINO_LOADW(WN, (CH) + 1 < p.nchunk ? (CH) + 1 : (CH));                                    \
+        WINO_LOADP();                                                                             \
+        __builtin_amdgcn_sched_barrier(0);      /* the loads stay in front of the matrix work (the scheduler would sink them to their first use) */ \
+        WINO_MFMA(VC, WC, 0);                                                                     \
+        if (MB == 2) {                                                                            \
+            f32x4 v1_[4];                                                                         \
+            WINO_READ(raw, bo0, MB - 1);                                                          \
+            WINO_XFORM(v1_, raw);                                                                 \
+            WINO_MFMA(v1_, WC, MB - 1);                                                           \
+        }                                                                                         \
+        WINO_READ(raw, bo1, 0);                                                                   \
+        WINO_XFORM(VN, raw);                                                                      \
+        WINO_COMMIT(bo2);                                                                         \
+        __syncthreads();                                                                          \
+        const int t_ = bo0; bo0 = bo1; bo1 = bo2; bo2 = t_;                                       \
+    } while (0)
+
+    // Software pipeline over three patch buffers.  The step of chunk c multiplies chunk c; the patch of chunk c + 2 is in flight
+    // (global -> registers) during it and committed to LDS at its end, so after the barrier that closes step c - 1 the image of
+    // chunk c + 1 is already readable: the first block's transform of chunk c + 1 is computed inside step c, under the matrix
+    // work of chunk c, and the first MFMA of a step issues right behind the barrier.  The loop is unrolled twice with the two
+    // register sets (weights, first operand) swapping roles: no copies.
+    f32x4 *smem4 = reinterpret_cast<f32x4 *>(smem);
+    int bo0 = 0, bo1 = PBUF, bo2 = 2 * PBUF;       // quad offsets of the buffers holding chunks c, c + 1, c + 2
+    WINO_LOADP();
+    WINO_COMMIT(bo0);
+    WINO_LOADP();
+    WINO_COMMIT(bo1);
+    WINO_LOADW(wA, 0);
+    __syncthreads();
+    f32x4 raw[8];
+    WINO_READ(raw, bo0, 0);
+    WINO_XFORM(vA, raw);
+    int chunk = 0;
+    for (; chunk + 1 < p.nchunk; chunk += 2) {
+        WINO_STEP(wA, vA, wB, vB, chunk);
+        WINO_STEP(wB, vB, wA, vA, chunk + 1);
+    }
+    if (chunk < p.nchunk) WINO_STEP(wA, vA, wB, vB, chunk);
+#undef WINO_LOADP
+#undef WINO_LOADW
+#undef WINO_COMMIT
+#undef WINO_READ
+#undef WINO_XFORM
+#undef WINO_MFMA
+#undef WINO_STEP
+
+    // ---- output transform.  acc[jp][mb][nw][4 rg + e] = M[(wave, jp)][cout 32 (nb0 + nw) + 8 rg + 4 g + e][tile n of block mb]
     // column half (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; row half across waves: Y[0] = R_0 + R_1 + R_2, Y[1] = R_1 - R_2 - R_3
-    f32x4 *xch = reinterpret_cast<f32x4 *>(smem);       // [mb][wave][q][rg][lane]
+    f32x4 *xch = reinterpret_cast<f32x4 *>(smem);       // [mb][nw][wave][q][rg][lane]
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            f32x4 m[4];
+        for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
-            for (int jp = 0; jp < 4; ++jp)
-                m[jp] = f32x4{acc[jp][mb][4 * rg + 0], acc[jp][mb][4 * rg + 1], acc[jp][mb][4 * rg + 2], acc[jp][mb][4 * rg + 3]};
-            xch[(((mb * 4 + wave) * 2 + 0) * 4 + rg) * 64 + lane] = (m[0] + m[1]) + m[2];
-            xch[(((mb * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = (m[1] - m[2]) - m[3];
-        }
+            for (int rg = 0; rg < 4; ++rg) {
+                f32x4 m[4];
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp)
+                    m[jp] = f32x4{acc[jp][mb][nw][4 * rg + 0], acc[jp][mb][nw][4 * rg + 1], acc[jp][mb][nw][4 * rg + 2], acc[jp][mb][nw][4 * rg + 3]};
+                xch[((((mb * NBW + nw) * 4 + wave) * 2 + 0) * 4 + rg) * 64 + lane] = (m[0] + m[1]) + m[2];
+                xch[((((mb * NBW + nw) * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = (m[1] - m[2]) - m[3];
+            }
     __syncthreads();
     const int pp = wave >> 1, qq = wave & 1;      // this wave finishes output pixel (pp, qq) of every tile
-    f32x4 bias4[4];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) bias4[rg] = *reinterpret_cast<const f32x4 *>(p.bias + nb * 32 + 8 * rg + 4 * g);
+    for (int nw = 0; nw < NBW; ++nw) {
+        const int cb = (nb0 + nw) * 32 + 4 * g;
+        f32x4 bias4[4];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int oy = y0 + 2 * (mb * 4 + (n >> 3)) + pp, ox = x0 + 2 * (n & 7) + qq;
-        const bool ok = oy < p.H && ox < p.W;
-        float *orow = p.out + (size_t)((b * p.H + (ok ? oy : 0)) * p.W + (ok ? ox : 0)) * p.out_stride + nb * 32 + 4 * g;
+        for (int rg = 0; rg < 4; ++rg) bias4[rg] = *reinterpret_cast<const f32x4 *>(p.bias + cb + 8 * rg);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 *x = xch + ((mb * 4 * 2 + qq) * 4 + rg) * 64 + lane;     // wave i at x[i * 2 * 4 * 64]
-            f32x4 y;
-            if (pp == 0) y = (x[0] + x[1 * 512]) + x[2 * 512];
-            else y = (x[1 * 512] - x[2 * 512]) - x[3 * 512];
-            y += bias4[rg];
-            if (p.lrelu) {
-                y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
+        for (int mb = 0; mb < MB; ++mb) {
+            const int oy = y0 + 2 * (mb * 4 + (n >> 3)) + pp, ox = x0 + 2 * (n & 7) + qq;
+            const bool ok = oy < p.H && ox < p.W;
+            float *orow = p.out + (size_t)((b * p.H + (ok ? oy : 0)) * p.W + (ok ? ox : 0)) * p.out_stride + cb;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 *x = xch + (((mb * NBW + nw) * 4 * 2 + qq) * 4 + rg) * 64 + lane;     // wave i at x[i * 2 * 4 * 64]
+                f32x4 y;
+                if (pp == 0) y = (x[0] + x[1 * 512]) + x[2 * 512];
+                else y = (x[1 * 512] - x[2 * 512]) - x[3 * 512];
+                y += bias4[rg];
+                if (p.lrelu) {
+                    y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
+                }
+                if (ok && cb + 8 * rg < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * rg) = y;
             }
-            if (ok && nb * 32 + 8 * rg + 4 * g < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * rg) = y;
         }
     }
 }
@@ -252,22 +332,23 @@ bool conv_wino_supports(int KH, int KW, int S, int padY, int padX)
     return KH == 3 && KW == 3 && S == 1 && padY == 1 && padX == 1;
 }
 
-template <int MB>
+template <int MB, int NBW>
 static int launch_w(const ConvParamsW &p, hipStream_t st)
 {
     constexpr int PH = 8 * MB + 2;
-    const size_t lds = std::max<size_t>((size_t)MB * 32768, (size_t)2 * (PH * WPW + 1) * WPIX * sizeof(float));
+    const size_t lds = std::max<size_t>((size_t)MB * NBW * 32768, (size_t)3 * (PH * WROWQ + WPIXQ) * 16);
     static LdsAttr attr;
-    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_wino_kernel<MB>), (int)lds)) return rc;
-    const long blocks = (long)p.B * cdiv(p.H, 8 * MB) * cdiv(p.W, 16) * (p.cout_pad / 32);
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_wino_kernel<MB, NBW>), (int)lds)) return rc;
+    const long blocks = (long)p.B * cdiv(p.H, 8 * MB) * cdiv(p.W, 16) * (p.cout_pad / (32 * NBW));
     PIV_REQUIRE(blocks < (1L << 31), "conv_wino: grid too large");
-    hipLaunchKernelGGL((conv_wino_kernel<MB>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_wino_kernel<MB, NBW>), dim3((unsigned)blocks), dim3(256), lds, st, p);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
 
-int launch_conv_w(const ConvParamsW &p, hipStream_t st)
+int launch_conv_w(const ConvParamsW &p_in, hipStream_t st)
 {
+    ConvParamsW p = p_in;
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.wpk && p.bias && p.out, "conv_wino: bad arguments");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0 && p.out_stride % 4 == 0,
                 "conv_wino: cout_pad=%d cout_store=%d out_stride=%d", p.cout_pad, p.cout_store, p.out_stride);
@@ -280,9 +361,23 @@ int launch_conv_w(const ConvParamsW &p, hipStream_t st)
         nchunk += (p.seg[s].cload + 7) / 8;
     }
     PIV_REQUIRE(nchunk == p.nchunk, "conv_wino: segments hold %d chunks, weights were packed for %d", nchunk, p.nchunk);
-    // 16-row blocks while they still give every CU two workgroups; the results do not depend on the choice (header)
-    const long blocks2 = (long)p.B * cdiv(p.H, 16) * cdiv(p.W, 16) * (p.cout_pad / 32);
-    return blocks2 >= 512 ? launch_w<2>(p, st) : launch_w<1>(p, st);
+    // Tile shape from the launch size; a value's summation order does not depend on it (header), so it may follow the batch.
+    const int nb = p.cout_pad / 32;
+    const long sp1 = (long)p.B * cdiv(p.H, 8) * cdiv(p.W, 16), sp2 = (long)p.B * cdiv(p.H, 16) * cdiv(p.W, 16);
+    int mb = sp2 * nb >= 512 ? 2 : 1;
+#ifdef PIVLFN_TOOLS
+    // A/B of the tile shapes (tools/bench_wino.py --masks): two or four channel blocks per wave halve / quarter the transform's
+    // vector work per MFMA but run one workgroup per CU (16 accumulators) or spill (1 x 2): measured slower, see DESIGN.md
+    const int force = PIV_KNOB(14);
+    if (force == 22 && nb % 2 == 0) return launch_w<2, 2>(p, st);
+    if (force == 14 && nb % 4 == 0) return launch_w<1, 4>(p, st);
+    if (force == 12 && nb % 2 == 0) return launch_w<1, 2>(p, st);
+    if (force == 21) mb = 2;
+    if (force == 11) mb = 1;
+#endif
+    (void)sp1;
+    if (mb == 2) return launch_w<2, 1>(p, st);
+    return launch_w<1, 1>(p, st);
 }
 
 }  // namespace pivlfn

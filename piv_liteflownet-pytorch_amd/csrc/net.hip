@@ -556,9 +556,10 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         return launch_conv_x(q, st);
     }
     // fp32 mode: the 3 x 3 / stride 1 layers by Winograd F(2x2, 3x3) on the fp32 matrix instruction (conv_wino.hip) from a
-    // 32 x 32 grid per image up; the bound is per image, never a function of the batch
+    // 64 x 64 grid per image up (a 32 x 32 grid is 32 workgroups with the whole K loop each: the split-K direct kernel is faster);
+    // the bound is per image, never a function of the batch
     if (t_precision == 0 && !res && cw.wpk_w && conv_wino_supports(cw.KH, cw.KW, S, padY, padX) &&
-        (long)Ho * Wo >= (PIV_KNOB(12) ? PIV_KNOB(12) : 32 * 32) && cout_store % 4 == 0) {
+        (long)Ho * Wo >= (PIV_KNOB(12) ? PIV_KNOB(12) : 64 * 64) && cout_store % 4 == 0) {
         ConvParamsW q;
         memset(&q, 0, sizeof(q));
         int i = 0;

@@ -22,14 +22,15 @@ import torch
 from .dist import gather_flows, shard_bounds
 from .flo import FloWriter
 from .inference import estimate
+from .pipeline import u8_to_input
 
 
 def frames_to_input(frames: torch.Tensor) -> torch.Tensor:
-    """uint8 [n,H,W] or [n,H,W,3] -> float32 [n,3,H,W] in [0,1] (grey frames replicated to three channels, /255)."""
-    x = frames.to(torch.float32).div_(255.0)
-    if x.dim() == 3:
-        return x[:, None].expand(-1, 3, -1, -1).contiguous()
-    return x.permute(0, 3, 1, 2).contiguous()
+    """uint8 [n,H,W] or [n,H,W,3] -> float32 [n,3,H,W] in [0,1] (grey frames replicated to three channels), the same bits as
+    ToTensor / run.py's input path: the table of correctly divided k/255 of `pipeline.u8_to_input`, not the GPU's `t * (1/255)`."""
+    if frames.dim() == 3:
+        frames = frames[..., None].expand(-1, -1, -1, 3)
+    return u8_to_input(frames.contiguous())
 
 
 def flow_file_name(pair_index: int) -> str:
@@ -69,8 +70,10 @@ def run_sequence(net, frames_fn: Callable[[int, int], torch.Tensor], n_frames: i
                 emitted += 1
 
     def sync() -> None:
+        # the compute stream only: a device-wide synchronize would also wait for the pending asynchronous all-gather (its own
+        # stream) and serialise it with the next chunk, which is exactly what the gather is asynchronous to avoid
         if on_gpu:
-            torch.cuda.synchronize(device)
+            torch.cuda.current_stream(device).synchronize()
 
     t_est = 0.0
     sync()
@@ -114,7 +117,8 @@ def run_sequence(net, frames_fn: Callable[[int, int], torch.Tensor], n_frames: i
         drain(pending)
     if writer is not None:
         writer.close()
-    sync()
+    if on_gpu:
+        torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     return {"pairs_total": n_pairs, "pairs_this_rank": hi - lo, "seconds": dt, "seconds_estimation": t_est,
             "flows_emitted": emitted}

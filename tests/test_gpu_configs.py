@@ -126,7 +126,8 @@ def _sequence_reference(dev, n_frames, S, seed):
     """estimate() pair by pair on the frames run_sequence renders."""
     net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
     fr = synth.ParticleSequence(S, S, seed=seed, device=dev).frames(0, n_frames)
-    x = fr.to(torch.float32).div_(255.0)[:, None].expand(-1, 3, -1, -1).contiguous()
+    from pivlfn.sequence import frames_to_input
+    x = frames_to_input(fr)          # the LUT conversion of run.py's input path (bit-identical to ToTensor)
     return net, [pivlfn.estimate(net, x[k:k + 1], x[k + 1:k + 2], tensor=False) for k in range(n_frames - 1)]
 
 

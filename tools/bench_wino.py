@@ -27,8 +27,13 @@ def main():
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--masks", default="", help="tools build only: ablation masks of the Winograd kernel (1 no MFMAs, 2 no weight loads, 4 no patch loads, 8 no epilogue)")
     a = ap.parse_args()
     lib = _lib.load()
+    if a.masks:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import _toolslib
+        lib = _toolslib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     layers = [tuple(int(v) for v in s.split("x")) for s in a.layers.split(",")] if a.layers else LAYERS
@@ -50,6 +55,16 @@ def main():
             def wino():
                 _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y["wino"].data_ptr(), co, a.batch, n, n, 1, st), "wino")
             fns = {"direct": direct, "wino": wino}
+            if a.masks:
+                fns = {}
+                for m in [int(v) for v in a.masks.split(",")]:
+                    def wm(m=m):
+                        lib.pivlfn_tune(13, m & 255)
+                        lib.pivlfn_tune(14, m >> 8)
+                        wino()
+                        lib.pivlfn_tune(13, 0)
+                        lib.pivlfn_tune(14, 0)
+                    fns[f"mask{m}"] = wm
             times = {k: [] for k in fns}
             for k in fns:
                 fns[k]()
@@ -65,6 +80,10 @@ def main():
                     torch.cuda.synchronize()
                     times[k].append(e0.elapsed_time(e1) / a.n * 1e3)
             flop = 2.0 * 9 * ci * co * n * n * a.batch
+            if a.masks:
+                print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: " + "   ".join(f"{k} min {min(v):8.1f} med {sorted(v)[len(v) // 2]:8.1f} us" for k, v in times.items()), flush=True)
+                lib.pivlfn_conv_destroy(h)
+                continue
             d = (y["wino"] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
             td, tw = min(times["direct"]), min(times["wino"])
             md, mw = sorted(times["direct"])[len(times["direct"]) // 2], sorted(times["wino"])[len(times["wino"]) // 2]

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--chunk", type=int, default=8, help="pairs per forward / per gather on every rank")
     ap.add_argument("--write", default=None, help="directory for rank 0's .flo files")
-    ap.add_argument("--precision", default="fp32_split3", choices=["fp32_split3", "fp32_split", "fp32", "fp16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"])
     ap.add_argument("--model", default="piv")
     ap.add_argument("--seed", type=int, default=99)
     a = ap.parse_args()
