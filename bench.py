@@ -40,11 +40,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-arithmetic", action="store_true", help="skip the side-by-side timing of the three fp32 conv arithmetics")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed warm runs of the CPU baseline (median reported)")
-    ap.add_argument("--precision", default="fp32_split3", choices=["fp32_split3", "fp32_split", "fp32", "fp16"],
-                    help="how the large convolutions multiply: fp32_split3 (the library's default: fp32 operands as two fp16 pieces, "
-                         "three partial products on the fp16 matrix cores, fp32 accumulation), fp32_split (three pieces, six partial "
-                         "products, exact to 2^-32), fp32 (the fp32 matrix instruction); fp16 = BASELINE config #5's reduced-precision "
-                         "mode, reported under its own metric name, never as the headline")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"],
+                    help="how the large convolutions multiply: fp32 (the library's default and the headline: the fp32 matrix instruction, "
+                         "3x3 stride-1 layers by Winograd F(2x2,3x3) in fp32), fp32_direct (the same instruction, direct convolution "
+                         "everywhere), fp32_split (fp32 operands as three fp16 pieces = all 24 bits, six partial products on the fp16 "
+                         "matrix cores, exact to 2^-32); fp32_split3 (two pieces, 22-23 operand bits) and fp16 (BASELINE config #5) are "
+                         "narrower than fp32 and reported under their own metric names, never as the headline")
     ap.add_argument("--profile-level", type=int, default=3, help="level whose warp+correlation launch is event-timed")
     return ap.parse_args()
 
@@ -119,24 +120,29 @@ def counter_traffic(name):
 
 
 DTYPE = {       # the arithmetic type the path computes in (short), and what that means (dtype_note)
-    "fp32_split3": ("f32 (products from fp16x3 split operands on the f16 MFMA, f32 accumulate)",
-                    "fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as two fp16 "
-                    "pieces: 3 partial products per fp32 product, relative product error <= 2^-21, layer outputs closer to float64 than the "
-                    "fp32 matrix instruction's; `arithmetic` times the fp32 instruction path in the same run"),
+    "fp32": ("f32",
+             "fp32 data, operands (all 24 bits), products and accumulators: v_mfma_f32_32x32x2_f32 in every convolution (exact fp32 fma chains); "
+             "the 3x3 stride-1 layers (95 % of the multiplies) by Winograd F(2x2,3x3) in fp32 -- the minimal-filtering algorithm cuDNN / MIOpen "
+             "use for fp32 3x3 layers: 2.25x fewer multiplies, input / output transforms are fp32 additions, filter transform in float64 rounded "
+             "once to fp32; error against a float64 convolution at or below the direct kernel's (tests/test_gpu_wino.py)"),
+    "fp32_direct": ("f32", "v_mfma_f32_32x32x2_f32, direct convolution in every layer"),
     "fp32_split": ("f32 (products from fp16x6 split operands on the f16 MFMA, f32 accumulate)",
                    "fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as three fp16 "
-                   "pieces: 6 partial products per fp32 product, exact to 2^-32; `arithmetic` times the fp32 instruction path in the same run"),
-    "fp32": ("f32", "v_mfma_f32_32x32x2_f32 in every convolution"),
+                   "pieces (all 24 bits): 6 partial products per fp32 product, exact to 2^-32"),
+    "fp32_split3": ("f32 data, 22-23-bit multiplicands (fp16x3 split operands on the f16 MFMA, f32 accumulate)",
+                    "NOT an fp32-wide arithmetic: each operand of the large convolutions enters the fp16 matrix cores as two fp16 pieces "
+                    "(22-23 significand bits), 3 partial products per product, relative product error <= 2^-21"),
     "fp16": ("f16 multiplicands, f32 accumulate", "BASELINE config #5: operands rounded to fp16"),
 }
+FP32_WIDE = ("fp32", "fp32_direct", "fp32_split")      # arithmetics that keep all 24 operand bits: only these may carry the fp32 metric name
 
 
 def arithmetic_modes(net, i1, i2, steps, dev):
-    """The same forward under each fp32-grade conv arithmetic, timed back to back in this process (single GPU): pairs/s and the
-    largest flow difference from the fp32 matrix instruction's result."""
+    """The same forward under each conv arithmetic, timed back to back in this process (single GPU): pairs/s and the largest flow
+    difference from the direct fp32-instruction result."""
     keep = net.precision
     res, ref = {}, None
-    for mode in ("fp32", "fp32_split", "fp32_split3"):
+    for mode in ("fp32_direct", "fp32", "fp32_split", "fp32_split3"):
         net.precision = mode
         for _ in range(3):
             flow = net(i1, i2)
@@ -149,18 +155,20 @@ def arithmetic_modes(net, i1, i2, steps, dev):
         if ref is None:
             ref = flow.clone()
         res[mode] = {"pairs_per_s": round(steps * i1.shape[0] / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
-                     "max_abs_px_vs_fp32_instruction": round(float((flow - ref).abs().max()), 7)}
+                     "max_abs_px_vs_fp32_direct": round(float((flow - ref).abs().max()), 7),
+                     "operand_bits": 24 if mode in FP32_WIDE else 23}
     net.precision = keep
-    res["what"] = ("fp32 = v_mfma_f32_32x32x2_f32 on every conv; fp32_split / fp32_split3 = the residual-free convs with >= 256x256 / "
-                   ">= 64x64 outputs per image on v_mfma_f32_32x32x16_f16 with fp32 operands split into 3 / 2 fp16 pieces (6 / 3 partial "
-                   "products, fp32 accumulate); "
-                   "layer-output error against float64 (tests/test_gpu_split.py): both splits 0.6 x the fp32 instruction's")
+    res["what"] = ("fp32_direct = v_mfma_f32_32x32x2_f32, direct convolution everywhere; fp32 (the headline) = the same instruction with the 3x3 "
+                   "stride-1 layers by Winograd F(2x2,3x3) in fp32; fp32_split / fp32_split3 = the residual-free convs with >= 256x256 / >= 64x64 "
+                   "outputs per image on v_mfma_f32_32x32x16_f16 with fp32 operands split into 3 / 2 fp16 pieces (6 / 3 partial products, fp32 "
+                   "accumulate); fp32_split3 keeps 22-23 operand bits and is not an fp32-wide arithmetic")
     return res
 
 
-def conv_roofline(dev, precision, launches=10):
+def conv_roofline(dev, precision, launches=40):
     """The dominant kernel of the forward -- the 128 -> 128 3x3 convolution of level 1 (1024 x 1024, batch 1) -- standalone through
-    the C ABI: matrix-core work actually executed per launch / its duration, against the dense MFMA peak of the instruction used."""
+    the C ABI: matrix-core work actually executed per launch / its duration, against the dense MFMA peak of the instruction used.
+    Every launch has its own event pair: min / median / max over `launches` launches."""
     import ctypes
     from pivlfn import _lib
     lib = _lib.load()
@@ -179,28 +187,42 @@ def conv_roofline(dev, precision, launches=10):
     def launch():
         if terms:
             _lib.check(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), ci, y.data_ptr(), co, 1, n, n, 1, 1, 1, 1, terms, st), "conv")
+        elif precision == "fp32":
+            _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), ci, y.data_ptr(), co, 1, n, n, 1, st), "conv")
         else:
             _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), co, None, 0, 1, n, n, 1, 1, 1, 1, st), "conv")
-    for _ in range(5):
+    for _ in range(10):
         launch()
-    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(launches):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for a, e in evs:
+        a.record()
         launch()
-    e.record()
+        e.record()
     torch.cuda.synchronize(dev)
     lib.pivlfn_conv_destroy(h)
-    t = a.elapsed_time(e) / launches * 1e-3
+    ts = sorted(a.elapsed_time(e) * 1e-3 for a, e in evs)
+    t = ts[len(ts) // 2]
+    spread = {"min_launch_us": round(ts[0] * 1e6, 1), "median_launch_us": round(t * 1e6, 1), "max_launch_us": round(ts[-1] * 1e6, 1),
+              "launches_timed": launches, "timer": "one hipEvent pair per launch on the launch stream (the pair's own ~10 us marker cost is included)"}
     flop = 2.0 * n * n * co * ci * 9
     if terms:
         return {"bound": "mfma", "achieved": round(terms * flop / t / 1e12, 1), "peak": 2516.0, "unit": "TFLOP/s", "frac": round(terms * flop / t / 2.516e15, 4),
                 "traffic": None, "kernel": f"conv_split kernels, 128->128 3x3 at 1024x1024 B=1, {terms} fp16 partial products per fp32 product (v_mfma_f32_32x32x16_f16)",
-                "fp32_equivalent_tflops": round(flop / t / 1e12, 1), "avg_launch_us": round(t * 1e6, 1), "launches_timed": launches,
+                "fp32_equivalent_tflops": round(flop / t / 1e12, 1), **spread,
                 "sustainable_on_random_operands_tflops": 1600.0,
-                "note": "fp16 matrix work actually executed (terms x 2 x pixels x Cin x Cout x 9) / duration; the chip sustains ~1600 TFLOP/s of this "
+                "note": "fp16 matrix work actually executed (terms x 2 x pixels x Cin x Cout x 9) / median duration; the chip sustains ~1600 TFLOP/s of this "
                         "instruction on random operands (1.70 GHz under power, tools/micro/mfma_f16_power.hip, profiles/r02_mfma_f16_power.log)"}
+    if precision == "fp32":
+        ex = flop / 2.25          # F(2x2,3x3): 16 multiplies per 2x2 output tile and channel pair instead of 36
+        return {"bound": "mfma", "achieved": round(ex / t / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ex / t / 157.3e12, 4), "traffic": None,
+                "kernel": "conv_wino_kernel<2,1>, 128->128 3x3 at 1024x1024 B=1 (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
+                "direct_equivalent_tflops": round(flop / t / 1e12, 1), **spread,
+                "note": "achieved = fp32 matrix work actually executed (2 x 16/4 x pixels x Cin x Cout) / median duration; the fp32 MFMA shares the SIMD's "
+                        "fp32 datapath with the vector instructions of the input / output transforms (no co-execution: profiles/r03_pmc_wino_insts.json), "
+                        "so the transforms' ~3 vector instructions per MFMA cost ~15 % of the peak by construction; clock under this kernel 2.39 GHz "
+                        "(GRBM_GUI_ACTIVE / duration, same file)"}
     return {"bound": "mfma", "achieved": round(flop / t / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(flop / t / 157.3e12, 4), "traffic": None,
-            "kernel": "conv_mfma2_kernel, 128->128 3x3 at 1024x1024 B=1 (v_mfma_f32_32x32x2_f32)", "avg_launch_us": round(t * 1e6, 1), "launches_timed": launches}
+            "kernel": "conv_mfma2_kernel, 128->128 3x3 at 1024x1024 B=1 (v_mfma_f32_32x32x2_f32)", **spread}
 
 
 def l3_throughput_regime(dev, batch=8, launches=40):
@@ -256,7 +278,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # PIVLFN_BENCH_FORCE_DIST=1: run the collective path with a process group of ONE rank (tests/test_gpu_configs.py executes the
+    # RCCL branch this way on the one-GPU box); MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE must then be set by the caller
+    use_dist = world > 1 or os.environ.get("PIVLFN_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -277,14 +302,14 @@ def main():
 
     div = 2 ** (net.lowest_level - 1)
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty(world * B, 2, S // div, S // div, device=gdev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty(world * B, 2, S // div, S // div, device=gdev) for _ in range(2)] if use_dist else None
     pending = [None, None]
 
     wait_s = [0.0]
 
     def step(i):
         flow = net(i1, i2)
-        if world > 1:
+        if use_dist:
             k = i & 1
             if pending[k] is not None:
                 tw = time.perf_counter()
@@ -297,7 +322,7 @@ def main():
         return flow
 
     def fence():
-        if world > 1:
+        if use_dist:
             for k in (0, 1):
                 if pending[k] is not None:
                     pending[k].wait()
@@ -315,6 +340,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         flow = step(i)
+    torch.cuda.current_stream(dev).synchronize()      # this rank's own forwards are done (not the pending gathers, not the other ranks)
     t_own = time.perf_counter() - t0            # this rank's own steps, before it waits for the others
     fence()
     dt = time.perf_counter() - t0
@@ -322,7 +348,7 @@ def main():
     if L:
         net.profile_enable(0)
     per_rank = [{"rank": 0, "pairs_per_s": round(args.steps * B / t_own, 3), "gather_wait_ms_per_step": 0.0}]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -360,24 +386,26 @@ def main():
                     "timer": "HIP start/stop events attached to the dispatch (hipExtLaunchKernelGGL) in every timed step, on the "
                              "stream the kernel runs on; event_record_pair_us = plain hipEventRecord pair around the same launch "
                              "(adds the marker packets' own cost); rocprofv3 average for the same kernel: profiles/"}
-        fp32_grade = args.precision != "fp16"
+        fp32_grade = args.precision in FP32_WIDE
         out = {
             "metric": (("PIV" if args.model == "piv" else "LiteFlowNet (Hui weights layout)") +
                        (f" image-pairs/s at {S}x{S} fp32" if fp32_grade else
-                        f" image-pairs/s at {S}x{S}, fp16-multiplicand conv mode (BASELINE config #5 variant; not the fp32 headline)")),
+                        (f" image-pairs/s at {S}x{S}, fp16-multiplicand conv mode (BASELINE config #5 variant; not the fp32 headline)" if args.precision == "fp16" else
+                         f" image-pairs/s at {S}x{S}, fp32 data with 22-23-bit multiplicands (three-term fp16 split; narrower than fp32, not the fp32 headline)"))),
             "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[args.precision][0], "dtype_note": DTYPE[args.precision][1], "data": "synthetic",
             "config": {"workload": f"{'PIV-LiteFlowNet-en' if args.model == 'piv' else 'LiteFlowNet'} forward, batch {B}/GPU, "
-                                   f"{S}x{S} synthetic PIV pair, " + ("fp32 (BASELINE configs[1])" if fp32_grade else "fp16-multiplicand convs"),
+                                   f"{S}x{S} synthetic PIV pair, " + ("fp32 (BASELINE configs[1])" if fp32_grade else ("fp16-multiplicand convs" if args.precision == "fp16" else "three-term split convs")),
                        "conv_arithmetic": args.precision,
                        "pairs_per_step_per_gpu": B, "weights": "generated (pivlfn.synth seed 0)",
                        "multi_gpu": "pairs sharded over ranks, async RCCL all-gather of flows per step" if world > 1 else "single GPU"},
             "roofline": roof,
-            "whole_net": {"conv_tflops_fp32_equivalent": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
+            "whole_net": {"conv_tflops_direct_equivalent": round(value * (2.506 if (args.model == 'piv' and S == 1024) else float('nan')) / world, 2),
                           "fp32_mfma_peak_tflops": 157.3,
-                          # against the fp32 instruction's peak: above 1 means the split path beats what that instruction can do at all
-                          "ratio_to_fp32_mfma_peak": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None,
+                          # multiplies of the DIRECT algorithm (2.506 TFLOP per pair) per second against the fp32 instruction's peak: Winograd
+                          # executes 2.25x fewer in the 3x3 stride-1 layers, so this may exceed what direct convolution could reach at all
+                          "direct_equivalent_ratio_to_fp32_mfma_peak": round(value / world * 2.506 / 157.3, 4) if (args.model == 'piv' and S == 1024) else None,
                           # layer-boundary bytes of the reference's graph (in + out + weights of every conv, fp32)
                           "layer_boundary_gb_per_pair": 16.57 if (args.model == 'piv' and S == 1024) else None,
                           "hbm_frac_of_8tbs": round(value / world * 16.57 / 8000.0, 4) if (args.model == 'piv' and S == 1024) else None},
@@ -393,9 +421,9 @@ def main():
                                       "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2]}
         if world == 1 and args.model == "piv" and S == 1024:
             out["roofline_batch8"] = l3_throughput_regime(dev)
-        if world == 1 and fp32_grade and args.model == "piv" and S == 1024:
+        if world == 1 and args.precision != "fp16" and args.model == "piv" and S == 1024:
             out["roofline_conv"] = conv_roofline(dev, args.precision)
-        if world == 1 and fp32_grade and not args.no_arithmetic:
+        if world == 1 and args.precision != "fp16" and not args.no_arithmetic:
             out["arithmetic"] = arithmetic_modes(net, i1, i2, min(args.steps, 10), dev)
         if not args.no_cpu_baseline and world == 1:
             ref, cb = cpu_baseline(args.model, S, wts, i1c, i2c, runs=args.cpu_runs)
@@ -406,7 +434,12 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if os.environ.get("PIVLFN_BENCH_FORCE_DIST") == "1" and rank == 0:
+            # what the one-rank RCCL run proves: the gathered buffer holds this rank's last flows
+            k = (args.steps - 1) & 1
+            same = bool(torch.equal(gathered[k].to(flow.device), flow)) if backend == "nccl" else None
+            print(json.dumps({"forced_dist": True, "backend": backend, "gathered_equals_flow": same}), flush=True)
         dist.destroy_process_group()
 
 

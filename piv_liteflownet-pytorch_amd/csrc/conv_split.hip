@@ -684,7 +684,11 @@ int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
         // 128 channels, 3 x 3, at least two 16-row tiles per CU and six K chunks: the one-workgroup-per-CU kernel (bit-identical
         // results; 128->128 at 1024^2: 841 -> 769 us, at 512^2: 221 -> 196; fewer tiles or chunks: its prologue does not pay)
         const long t16 = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 16) * p.B;
-        const bool fits31 = (size_t)p.H * p.W * 4 * 160 < ((size_t)1 << 31);      // 32-bit buffer offsets inside one image
+        // 32-bit buffer offsets inside one image of every source (the 16-row kernel's descriptors and per-lane offsets are 32-bit;
+        // computed from the real pixel strides: a wide caller tensor sends the layer to the small-tile kernel instead)
+        bool fits31 = true;
+        for (int i = 0; i < p.nseg; ++i)
+            fits31 = fits31 && ((size_t)p.H * p.W * (size_t)p.seg[i].stride + (size_t)p.seg[i].cload) * 4 < ((size_t)1 << 31);
         // A folded tail (p.wtail) only exists for this kernel and sums in another order than the zero-padded tail chunk of the
         // others: for layers that have one, the kernel is chosen from the per-image tile count (a pair's bits must not depend on
         // its batch mates); layers without a tail give the same bits on every kernel and may follow the batch.

@@ -539,7 +539,7 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
     // kernel has 4-row tiles and split-K for the small grids; below 64x64 the layers are a dependent chain of ~12 us launches on
     // either kernel).  The six-term kernel has neither and keeps the 256x256 bound.  Per image: the choice never depends on the
     // batch (tools/split_threshold.py: 1024^2, 512^2 and 256^2 inputs).
-    if (t_precision >= 2 && !res && cw.wpk_x && conv_split_supports(cw.KH, cw.KW, S, cw.cout_pad, t_precision == 3 ? 3 : 6) &&
+    if ((t_precision == 2 || t_precision == 3) && !res && cw.wpk_x && conv_split_supports(cw.KH, cw.KW, S, cw.cout_pad, t_precision == 3 ? 3 : 6) &&
         (long)Ho * Wo >= (PIV_KNOB(11) ? PIV_KNOB(11) : (t_precision == 3 ? 64 * 64 : 256 * 256))) {
         ConvParamsX q;
         memset(&q, 0, sizeof(q));
@@ -639,7 +639,19 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     q.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
     q.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
     q.nchunk = c->cw.nchunk_x; q.lrelu = leaky;
+    // one image's worth of split-K scratch: larger batches run image by image, so the split factor -- hence the summation order and
+    // the bits of a sample -- is the same whatever the batch (the invariant launch_conv_x states for the network's own calls)
     q.scratch = c->scratch; q.scratch_floats = KSPLIT_FLOATS;
+    if (B > 1 && (long)cdiv(q.Wo, 32) * cdiv(q.Ho, 4) * (q.cout_pad / 32) <= 256) {      // the grids launch_conv_x may split
+        for (int b = 0; b < B; ++b) {
+            ConvParamsX qb = q;
+            qb.B = 1;
+            qb.seg[0].ptr = x + (size_t)b * H * W * x_stride;
+            qb.out = y + (size_t)b * q.Ho * q.Wo * y_stride;
+            if (int rc = launch_conv_x(qb, st)) return rc;
+        }
+        return PIVLFN_OK;
+    }
     return launch_conv_x(q, st);
 }
 
@@ -694,6 +706,19 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     // restores the level-3 features whatever the order, and all of it after NetC is the faster step (10.58 vs 10.70 ms,
     // tools/net_ab.py --masks 0,4096, three interleaved rounds) -- the default again; the early order stays selectable in the tools build.
     const hipStream_t side = (PIV_KNOB(1) & 2048) ? st : net->side;        // tools A/B: everything on one stream
+    // Whatever path leaves this function -- also an early error return -- the main stream joins every piece of side-stream work
+    // that was forked and not yet waited for: an un-joined fork would invalidate a stream capture and let the side kernels run on
+    // into the caller's next use of the workspace.
+    struct SideJoin {
+        hipStream_t st;
+        hipEvent_t *ev;
+        unsigned pending = 0;
+        ~SideJoin()
+        {
+            for (int L = 0; L < 7; ++L)
+                if (pending & (1u << L)) (void)hipStreamWaitEvent(st, ev[L], 0);
+        }
+    } side_join{st, net->ev_join};
     const bool side_early = (PIV_KNOB(1) & 4096) != 0;                     // tools A/B: 4096 = each level's share right behind its NetC layer
     auto side_level = [&](int L) -> int {
         if (L < net->lowest || L > 4) return PIVLFN_OK;
@@ -705,6 +730,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         if (L <= 2)
             RUN(conv(net->ext[L], {{bf.feat[L], 32, 32}}, bf.ext[L], 64, 64, nullptr, 0, 1, N2, h[L], w[L], 1, 0, 0, side));
         PIV_CHECK_HIP(hipEventRecord(net->ev_join[L], side));
+        if (side != st) side_join.pending |= 1u << L;
         return PIVLFN_OK;
     };
     // NetC on both frames as one batch of 2B (:325-326, Features.forward :108-116)
@@ -731,8 +757,9 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     // chip) brings them back.  Nothing depends on it; it is joined at the end of the forward.
     bool touched = false;
     if (side != st && net->lowest <= 3 && !(PIV_KNOB(1) & 16384)) {
-        RUN(launch_touch(bf.feat[3], N2 * h[3] * w[3] * C_FEAT[3], bf.mean, side));
+        RUN(launch_touch(bf.feat[3], (size_t)N2 * h[3] * w[3] * C_FEAT[3], bf.mean, side));
         PIV_CHECK_HIP(hipEventRecord(net->ev_join[6], side));      // joined at the very end of the forward (stream capture needs it)
+        side_join.pending |= 1u << 6;
         touched = true;
     }
 
@@ -753,7 +780,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         // Join the side stream only where its results are first read: NetC_ext feeds Matching at levels <= 2, moduleFeat feeds
         // Regularization at levels 3 and 4.  (A cross-queue wait costs a barrier packet and a cold start for the next
         // kernel: in front of the level-3 warp+correlation it cost that launch 2 us.)
-        if (L <= 2) PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0));
+        if (L <= 2) { PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0)); side_join.pending &= ~(1u << L); }
         // ---- Matching (:165-187)
         const float *fup = nullptr;
         if (prev) {
@@ -819,7 +846,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         // ---- Regularization (:274-303); note it takes the RAW NetC feature (:361)
         RUN(launch_flow_mean(bf.flowS, bf.partial, bf.mean, B, hh * ww, st));
         RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, sc, bf.misc4, B, hh, ww, st));
-        if (L == 3 || L == 4) PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0));
+        if (L == 3 || L == 4) { PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0)); side_join.pending &= ~(1u << L); }
         const float *fr = L < 5 ? bf.featR[L] : f1raw;
         const int cfr = L < 5 ? 128 : cf;
         RUN(conv(lw.R[0], {{fr, cfr, cfr}, {bf.misc4, 4, 4}}, bf.t128a, 128, 128, nullptr, 0, 1, B, hh, ww, 1, 1, 1, st, 0, h16));
@@ -846,7 +873,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         prev = cur;
         cur = (cur == bf.flowA) ? bf.flowB : bf.flowA;
     }
-    if (touched) PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[6], 0));
+    if (touched) { PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[6], 0)); side_join.pending &= ~(1u << 6); }
 #undef RUN
     return PIVLFN_OK;
 }

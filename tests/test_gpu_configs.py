@@ -42,7 +42,6 @@ def test_config0_run_py_hui_256_pair(tmp_path, dev):
     """`run.py --model hui -p` on 256x256 pairs: one synthetic particle pair and the reference's own demo pair
     (tests/golden/DNS_turbulence_img{1,2}.tif, grey TIFFs) -> .flo files against the oracle's estimate() on the CPU."""
     import PIL.Image
-    import run as runpy
     d = tmp_path / "pairs"
     d.mkdir()
     a, b, _ = synth.particle_pair(256, 256, 4242)
@@ -72,7 +71,6 @@ def test_config0_run_py_brightness_contrast(tmp_path, dev):
     <prefix>_<BBB>_<CCC>_<suffix>_out.flo, equal to Inference.parser on PIL images enhanced the way the reference does."""
     import PIL.Image
     import PIL.ImageEnhance
-    import run as runpy
     seq = tmp_path / "seq"
     seq.mkdir()
     frames = []
@@ -200,6 +198,84 @@ def test_bench_py_two_rank_rehearsal(dev):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["unit"] == "image-pairs/s"
     assert j["value"] > 0 and len(j["per_rank"]) == 2
     assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01                  # value = all ranks' pairs / max time
+
+
+def test_rccl_branch_executes_on_one_rank(dev, tmp_path):
+    """The `nccl` (= RCCL) code paths, which the gloo rehearsals replace, executed for real in a fresh child with a process group
+    of one rank on this one GPU: bench.py's init_process_group("nccl", device_id=...) + asynchronous all_gather_into_tensor +
+    barrier + all_reduce(MAX), and pivlfn.dist.gather_flows on device tensors (synchronous and asynchronous)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--size", "256", "--no-cpu-baseline",
+           "--no-arithmetic"]
+    outs = _run_children(lambda r: cmd, 1, {"PIVLFN_BENCH_FORCE_DIST": "1", "PIVLFN_BENCH_BACKEND": "nccl"})
+    lines = [json.loads(ln) for ln in outs[0][1].splitlines() if ln.startswith("{")]
+    main = [j for j in lines if "metric" in j]
+    forced = [j for j in lines if j.get("forced_dist")]
+    assert len(main) == 1 and len(forced) == 1
+    assert forced[0]["backend"] == "nccl" and forced[0]["gathered_equals_flow"] is True
+    j = main[0]
+    assert j["n_gpus"] == 1 and j["value"] > 0 and len(j["per_rank"]) == 1
+    # the rank's own rate is timed after its stream has drained: the same thing as `value` on one rank (not the host's enqueue rate)
+    assert abs(j["per_rank"][0]["pairs_per_s"] - j["value"]) / j["value"] < 0.2, (j["per_rank"], j["value"])
+    script = tmp_path / "gather_nccl.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'piv_liteflownet-pytorch_amd')!r})\n"
+        "from pivlfn.dist import gather_flows\n"
+        "torch.cuda.set_device(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "x = torch.randn(3, 2, 64, 96, device=dev)\n"
+        "full = gather_flows(x, 3)\n"
+        "work, finish = gather_flows(x * 2, 3, async_op=True)\n"
+        "y = finish()\n"
+        "torch.cuda.synchronize()\n"
+        "ok = torch.equal(full, x) and torch.equal(y, x * 2) and full.is_cuda and dist.get_backend() == 'nccl'\n"
+        "dist.destroy_process_group()\n"
+        "print('GATHER_OK' if ok else 'GATHER_BAD')\n")
+    outs = _run_children(lambda r: [sys.executable, str(script)], 1, {})
+    assert "GATHER_OK" in outs[0][1], outs[0]
+
+
+def test_real_weights_file_through_run_py(tmp_path, dev):
+    """run.py --weights on a state-dict FILE (reference: run.py:71-83 `get_weights` = torch.load of a .paramOnly, :217-226): a seeded
+    state dict is written with torch.save under the reference's file name, run.py loads it and estimates the reference's own demo
+    pair; the .flo equals estimate() with the same weights loaded in memory.  Also records the largest activation magnitude of
+    every layer on that pair (from the CPU oracle): the head-room of the opt-in split modes, whose inputs must stay below 65504."""
+    import shutil
+    wts = synth.generate_weights("piv", 0)
+    wfile = tmp_path / "PIV-LiteFlowNet-en.paramOnly"
+    torch.save(wts, str(wfile))
+    indir = tmp_path / "demo"
+    indir.mkdir()
+    for k in (1, 2):
+        shutil.copy(os.path.join(ROOT, "tests", "golden", f"DNS_turbulence_img{k}.tif"), indir / f"DNS_turbulence_img{k}.tif")
+    outdir = tmp_path / "out"
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "piv_liteflownet-pytorch_amd", "run.py"), "--model", "piv", "-p", "-i", str(indir),
+                         "-o", str(outdir), "--weights", str(wfile)], capture_output=True, text=True, cwd=ROOT)
+    assert rc.returncode == 0, rc.stderr[-3000:]
+    flos = [os.path.join(d, f) for d, _, fs in os.walk(outdir) for f in fs if f.endswith(".flo")]
+    assert len(flos) == 1
+    got = read_flow(flos[0])
+    from pivlfn.pipeline import read_image_u8 as _rd, u8_to_input
+    a = torch.from_numpy(_rd(str(indir / "DNS_turbulence_img1.tif")))[None]
+    b = torch.from_numpy(_rd(str(indir / "DNS_turbulence_img2.tif")))[None]
+    net = pivlfn.piv_liteflownet(torch.load(str(wfile))).to(dev).eval()
+    want = pivlfn.estimate(net, u8_to_input(a.to(dev)), u8_to_input(b.to(dev)), tensor=False)
+    assert got.shape == (256, 256, 2) and np.array_equal(got, want)
+    # per-layer activation range on this pair (oracle = CPU restatement of the reference's forward, test infrastructure)
+    from unittest import mock
+    onet = orc.make_net("piv", wts, corr="c")
+    peaks = []
+    real_conv2d = orc.F.conv2d
+
+    def spy(x, *a, **k):
+        peaks.append(float(x.abs().max()))           # what a convolution layer is fed
+        return real_conv2d(x, *a, **k)
+    with mock.patch.object(orc.F, "conv2d", spy), torch.no_grad():
+        onet.forward(u8_to_input(a), u8_to_input(b))
+    top = max(peaks) if peaks else 0.0
+    print(f"largest |input| over {len(peaks)} convolution calls on the demo pair: {top:.3g} (fp16 range of the split modes' leading piece: 65504)")
+    assert peaks and top < 65504 / 64, "seeded weights leave less than 6 binades of head-room for the opt-in split modes"
 
 
 # ---- configs[4] ---------------------------------------------------------------------------------------------------

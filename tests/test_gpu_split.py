@@ -304,3 +304,25 @@ def test_split_kernel_properties_at_full_size(terms, dev):
     assert torch.equal(ysft[:, dy + 1:S - 1, dx + 1:S - 1], y[:, 1:S - dy - 1, 1:S - dx - 1])     # (the last row / column see the zero padding)
     y2 = _conv_split(w, zero_b, x * 2.0, terms, dev)
     assert torch.equal(y2, y * 2.0)
+
+
+def test_split_modes_outside_the_fp16_range_give_nan_not_a_wrong_number(dev):
+    """The split kernels' leading piece is an fp16: an input of magnitude >= 65504 overflows it and the affected outputs are NaN /
+    non-finite (include/pivlfn.h) -- never a silently saturated, plausible-looking value; the fp32 kernels (direct and Winograd)
+    take the same layer in their stride.  The split modes are opt-in for this reason (the library default is 'fp32')."""
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17
+    b = torch.zeros(64)
+    x = torch.randn(1, 64, 64, 32, generator=g)
+    x[0, 20, 30, 5] = 1.0e5                                   # one out-of-range activation
+    for terms in (3, 6):
+        y = _conv_split(w, b, x, terms, dev)
+        hit = y[0, 19:22, 29:32, :]                           # its 3 x 3 receptive neighbourhood
+        assert not torch.isfinite(hit).all(), f"{terms}-term split returned finite values for an input outside the fp16 range"
+        far = y[0, :10, :10, :]
+        assert torch.isfinite(far).all()
+    from test_gpu_wino import run_wino
+    from test_gpu_conv import Conv
+    yw = run_wino(Conv(w, b), x.permute(0, 3, 1, 2).contiguous(), False, dev)
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1)
+    assert torch.isfinite(yw).all() and (yw.double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
