@@ -139,13 +139,13 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 
 // patch of chunk `lchunk` -> pr (voffset = the slot's record, soffset = the chunk's channel offset), then advance to the next chunk;
 // past the end the last chunk is fetched again (into a buffer nobody reads any more): the loop body has no branch around a load
-#define WINO_LOADP()                                                                              \
+#define WINO_LOADP(PR)                                                                            \
     do {                                                                                          \
         const int scl_ = seg == 0 ? sclv[0] : (seg == 1 ? sclv[1] : sclv[2]);                     \
         const __amdgpu_buffer_rsrc_t rs_ = seg == 0 ? rsv[0] : (seg == 1 ? rsv[1] : rsv[2]);      \
         const bool qok_ = c0 + q4 < scl_;                                                         \
         _Pragma("unroll") for (int s = 0; s < PS; ++s)                                            \
-            pr[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? pvo[s] : WOOB), c0 * 4, 0)); \
+            PR[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? pvo[s] : WOOB), c0 * 4, 0)); \
         if (lchunk + 1 < p.nchunk) {                                                              \
             ++lchunk;                                                                             \
             c0 += 8;                                                                              \
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
             _Pragma("unroll") for (int jp = 0; jp < 4; ++jp)                                      \
                 WN[nw][jp] = *reinterpret_cast<const f32x4 *>(w_ + nw * 4096 + jp * 256 + lane * 4); \
     } while (0)
-#define WINO_COMMIT(BOFF)                                                                         \
+#define WINO_COMMIT(PR, BOFF)                                                                     \
     do {                                                                                          \
-        _Pragma("unroll") for (int s = 0; s < PS; ++s) smem4[(BOFF) + plds[s]] = pr[s];          \
+        _Pragma("unroll") for (int s = 0; s < PS; ++s) smem4[(BOFF) + plds[s]] = PR[s];          \
     } while (0)
 // the lane's 8 operand quads of block MB_ (rows ra, rb x columns 0..3 of its tile's patch) from the patch image at quad offset BOFF
 #define WINO_READ(RAW, BOFF, MB_)                                                                 \
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 #define WINO_STEP(WC, VC, WN, VN, CH)                                                             \
     do {                                                                                          \
         WINO_LOADW(WN, (CH) + 1 < p.nchunk ? (CH) + 1 : (CH));                                    \
-        WINO_LOADP();                                                                             \
+        WINO_LOADP(pr);                                                                           \
         __builtin_amdgcn_sched_barrier(0);      /* the loads stay in front of the matrix work (the scheduler would sink them to their first use) */ \
         WINO_MFMA(VC, WC, 0);                                                                     \
         if (MB == 2) {                                                                            \
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
         }                                                                                         \
         WINO_READ(raw, bo1, 0);                                                                   \
         WINO_XFORM(VN, raw);                                                                      \
-        WINO_COMMIT(bo2);                                                                         \
+        WINO_COMMIT(pr, bo2);                                                                     \
         __syncthreads();                                                                          \
         const int t_ = bo0; bo0 = bo1; bo1 = bo2; bo2 = t_;                                       \
     } while (0)
@@ -222,11 +222,14 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     // register sets (weights, first operand) swapping roles: no copies.
     f32x4 *smem4 = reinterpret_cast<f32x4 *>(smem);
     int bo0 = 0, bo1 = PBUF, bo2 = 2 * PBUF;       // quad offsets of the buffers holding chunks c, c + 1, c + 2
-    WINO_LOADP();
-    WINO_COMMIT(bo0);
-    WINO_LOADP();
-    WINO_COMMIT(bo1);
-    WINO_LOADW(wA, 0);
+    {   // prologue: the first two patches and the first weights all in flight together (one memory round trip, not two)
+        f32x4 pr2[PS];
+        WINO_LOADW(wA, 0);
+        WINO_LOADP(pr);
+        WINO_LOADP(pr2);
+        WINO_COMMIT(pr, bo0);
+        WINO_COMMIT(pr2, bo1);
+    }
     __syncthreads();
     f32x4 raw[8];
     WINO_READ(raw, bo0, 0);

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--ab", default="", help="path of a second build of libpivlfn.so: its Winograd kernel is timed beside the current one (interleaved rounds)")
     ap.add_argument("--masks", default="", help="tools build only: ablation masks of the Winograd kernel (1 no MFMAs, 2 no weight loads, 4 no patch loads, 8 no epilogue)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -34,6 +35,13 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import _toolslib
         lib = _toolslib.load()
+    lib_b = None
+    if a.ab:
+        lib_b = ctypes.CDLL(a.ab)
+        for name, (res, args) in _lib.SIGNATURES.items():
+            if hasattr(lib_b, name):
+                fn = getattr(lib_b, name)
+                fn.restype, fn.argtypes = res, args
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
     layers = [tuple(int(v) for v in s.split("x")) for s in a.layers.split(",")] if a.layers else LAYERS
@@ -55,6 +63,14 @@ def main():
             def wino():
                 _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y["wino"].data_ptr(), co, a.batch, n, n, 1, st), "wino")
             fns = {"direct": direct, "wino": wino}
+            if lib_b is not None:
+                hb = ctypes.c_void_p()
+                _lib.check(lib_b.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(hb)), "create b")
+                y["prev"] = torch.empty(a.batch, n, n, co, device=dev)
+
+                def prev():
+                    assert lib_b.pivlfn_conv2d_nhwc_wino(hb, x.data_ptr(), xs, y["prev"].data_ptr(), co, a.batch, n, n, 1, st) == 0
+                fns = {"wino": wino, "prev": prev}
             if a.masks:
                 fns = {}
                 for m in [int(v) for v in a.masks.split(",")]:
@@ -80,8 +96,22 @@ def main():
                     torch.cuda.synchronize()
                     times[k].append(e0.elapsed_time(e1) / a.n * 1e3)
             flop = 2.0 * 9 * ci * co * n * n * a.batch
+            if lib_b is not None:
+                tw, tp = min(times["wino"]), min(times["prev"])
+                mw, mp = sorted(times["wino"])[len(times["wino"]) // 2], sorted(times["prev"])[len(times["prev"]) // 2]
+                print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: current min {tw:8.1f} med {mw:8.1f} us   previous build min {tp:8.1f} med {mp:8.1f} us   "
+                      f"current/previous {tw / tp:5.3f} (min) {mw / mp:5.3f} (med)   bits equal: {bool(torch.equal(y['wino'], y['prev']))}", flush=True)
+                lib_b.pivlfn_conv_destroy(hb)
+                lib.pivlfn_conv_destroy(h)
+                continue
             if a.masks:
-                print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: " + "   ".join(f"{k} min {min(v):8.1f} med {sorted(v)[len(v) // 2]:8.1f} us" for k, v in times.items()), flush=True)
+                direct()
+                diffs = {}
+                for k in fns:
+                    y["wino"].fill_(float("nan"))
+                    fns[k]()
+                    diffs[k] = (y["wino"] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
+                print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: " + "   ".join(f"{k} min {min(v):8.1f} med {sorted(v)[len(v) // 2]:8.1f} us (diff {diffs[k]:.1e})" for k, v in times.items()), flush=True)
                 lib.pivlfn_conv_destroy(h)
                 continue
             d = (y["wino"] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
