@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--model", default="piv", choices=["piv", "hui"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-arithmetic", action="store_true", help="skip the side-by-side timing of the three fp32 conv arithmetics")
+    ap.add_argument("--lean", action="store_true", help="only the timed forwards (no level-1 / batch-8 / conv roofline extras): for profiler runs")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed warm runs of the CPU baseline (median reported)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"],
                     help="how the large convolutions multiply: fp32 (the library's default and the headline: the fp32 matrix instruction, "
@@ -256,7 +257,7 @@ def l3_throughput_regime(dev, batch=8, launches=40):
     torch.cuda.synchronize(dev)
     t = a.elapsed_time(b) / launches * 1e-3
     alg = l3_algorithmic_bytes(batch, 1024, 1024, 3, C, s)
-    traffic, traffic_src = counter_traffic("r02_pmc_l3b8_warp_corr.json") if batch == 8 else (None, "no counter pass for this batch")
+    traffic, traffic_src = counter_traffic("r03_pmc_l3b8_warp_corr.json") if batch == 8 else (None, "no counter pass for this batch")
     return {"bound": "hbm", "achieved": round(alg / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / t / 8e12, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(t * 1e6, 2), "algorithmic_bytes_per_launch": alg, "launches_timed": launches,
@@ -358,7 +359,7 @@ def main():
         per_rank = [{"rank": r, "pairs_per_s": round(float(v[0]), 3), "gather_wait_ms_per_step": round(float(v[1]), 4)} for r, v in enumerate(allr)]
     # level-1 launch of the same kernel family (395 MB: beyond the 256 MiB Infinity Cache), timed the same way in a few extra steps
     l1 = None
-    if L == 3 and world == 1 and args.model == "piv" and args.size == 1024 and net.lowest_level == 1:
+    if L == 3 and world == 1 and args.model == "piv" and args.size == 1024 and net.lowest_level == 1 and not args.lean:
         net.profile_enable(1)
         for i in range(5):
             step(i)
@@ -377,7 +378,7 @@ def main():
             t_k = k_ms / k_n * 1e-3                       # start/stop events attached to the dispatch itself
             t_pair = k_empty_ms / k_n * 1e-3              # plain hipEventRecord pair around the same launch (incl. marker cost)
             ach = alg / t_k / 1e9
-            traffic, traffic_src = (counter_traffic("r02_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
+            traffic, traffic_src = (counter_traffic("r03_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
                                     else (None, "no counter pass for this workload"))
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": f"warp_corr_kernel (level {L}: C={C}, stride {stride})",
@@ -414,14 +415,14 @@ def main():
         if l1 is not None and l1[2]:
             alg1 = l3_algorithmic_bytes(B, S, S, 1, 64, 2)
             t1 = l1[0] / l1[2] * 1e-3
-            tr1, src1 = counter_traffic("r02_pmc_l1_warp_corr.json") if B == 1 else (None, "no counter pass for this workload")
+            tr1, src1 = counter_traffic("r03_pmc_l1_warp_corr.json") if B == 1 else (None, "no counter pass for this workload")
             out["roofline_level1"] = {"bound": "hbm", "achieved": round(alg1 / t1 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                       "frac": round(alg1 / t1 / 8e12, 4), "traffic": tr1, "traffic_source": src1,
                                       "kernel": "warp_corr_kernel (level 1: C=64, stride 2; 395 MB per launch, beyond the Infinity Cache)",
                                       "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2]}
-        if world == 1 and args.model == "piv" and S == 1024:
+        if world == 1 and args.model == "piv" and S == 1024 and not args.lean:
             out["roofline_batch8"] = l3_throughput_regime(dev)
-        if world == 1 and args.precision != "fp16" and args.model == "piv" and S == 1024:
+        if world == 1 and args.precision != "fp16" and args.model == "piv" and S == 1024 and not args.lean:
             out["roofline_conv"] = conv_roofline(dev, args.precision)
         if world == 1 and args.precision != "fp16" and not args.no_arithmetic:
             out["arithmetic"] = arithmetic_modes(net, i1, i2, min(args.steps, 10), dev)

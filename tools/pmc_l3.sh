@@ -11,7 +11,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $grp | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/$tag" -- $CMD > "$OUT/$tag.log" 2>&1
 done
-python3 tools/pmc_summary.py "$OUT" 3 > "$OUT/r02_pmc_l3_warp_corr.json"
-python3 tools/pmc_summary.py "$OUT" 1 > "$OUT/r02_pmc_l1_warp_corr.json"
-python3 tools/pmc_summary.py "$OUT" 3 8 > "$OUT/r02_pmc_l3b8_warp_corr.json"
-cat "$OUT/r02_pmc_l3_warp_corr.json" "$OUT/r02_pmc_l1_warp_corr.json" "$OUT/r02_pmc_l3b8_warp_corr.json"
+python3 tools/pmc_summary.py "$OUT" 3 > "$OUT/r03_pmc_l3_warp_corr.json"
+python3 tools/pmc_summary.py "$OUT" 1 > "$OUT/r03_pmc_l1_warp_corr.json"
+python3 tools/pmc_summary.py "$OUT" 3 8 > "$OUT/r03_pmc_l3b8_warp_corr.json"
+cat "$OUT/r03_pmc_l3_warp_corr.json" "$OUT/r03_pmc_l1_warp_corr.json" "$OUT/r03_pmc_l3b8_warp_corr.json"
