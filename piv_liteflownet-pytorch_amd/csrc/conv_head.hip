@@ -7,6 +7,7 @@
 //   * the 2 x 32 x k x k weights are read through the scalar cache (wave-uniform addresses -> s_load), so each FMA
 //     takes its weight from an SGPR and one 16-byte LDS read feeds 8 FMAs (balanced LDS : VALU on CDNA4);
 //   * output is the network's 4-lane flow layout (u, v, 0, 0).
+#include <algorithm>
 #include "common.h"
 
 namespace pivlfn {
@@ -166,6 +167,110 @@ __global__ __launch_bounds__(256, 3) void conv_head4_kernel(const float *__restr
     }
 }
 
+// ---- large images, wide kernels: the head as a (K x 1) convolution on the fp32 matrix cores + a diagonal sum -----------------
+// out[y][x][o] = b[o] + sum_kx T[y][x + kx - p][o, kx],   T[y][x'][o, kx] = sum_{ky, c} in[y + ky - p][x'][c] * w[o][c][ky][kx].
+// T is a vertical (K x 1) convolution from 32 to 2 x K <= 16 channels: on v_mfma_f32_16x16x4_f32 (M = the 16 (o, kx) slots, N = 16
+// pixels of a row, K = 4 channels) it wastes 2 of 16 output rows at K = 7 instead of the 30 of 32 columns the plain head would, and
+// needs 3.5 MFMAs per pixel: 48 us of matrix time at 1024^2 where the vector kernel above is LDS-bound at 150 us.
+//   * workgroup = 4 waves = a strip of 64 columns (58 outputs + the 6-column halo of the diagonal sum) x 16 rows; wave w owns
+//     columns 16 w .. 16 w + 15 of all rows.  No LDS and no barrier in the matrix phase: the B operand (16 pixels x 16 channels per
+//     16-byte load) comes straight from global memory through a buffer descriptor (rows and columns outside the image read as
+//     zeros: the convolution's padding), every input row is loaded once and feeds the K output rows it belongs to; the A operand
+//     (weights, 2 K fragments packed at load time) stays in registers;
+//   * the T tile goes through LDS (8 rows x 64 columns x 16 slots at a time) for the diagonal sum, bias and residual; output in the
+//     4-lane flow layout.
+using f32x4h = __attribute__((ext_vector_type(4))) float;
+template <int K, int TH>
+__global__ __launch_bounds__(256) void conv_head_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             float b0, float b1, const float *__restrict__ res4,
+                                                             float *__restrict__ out4, int B, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int P = K / 2, TWO = 64 - 2 * P;
+    const int tiles_x = (W + TWO - 1) / TWO, tiles_y = (H + TH - 1) / TH;
+    int bid = xcd_remap(blockIdx.x, tiles_x * tiles_y * B);
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int xs0 = tx * TWO - P, y0 = ty * TH;          // first column of the strip (may be negative), first output row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+
+    // weight fragments, packed at load time behind the vector kernels' table (pack_head): one 16-byte load per (ky, half)
+    f32x4h A[K][2];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) A[ky][h] = *reinterpret_cast<const f32x4h *>(w + K * K * 64 + ((ky * 2 + h) * 64 + lane) * 4);
+
+    const size_t img = (size_t)H * W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)b * img * 32), 0, (unsigned)(img * 32 * sizeof(float)), 0x00020000);
+    const int xs = xs0 + 16 * wave + n16;              // this lane's column
+    const bool xin = xs >= 0 && xs < W;
+    f32x4h acc[TH];
+#pragma unroll
+    for (int i = 0; i < TH; ++i) acc[i] = f32x4h{0.f, 0.f, 0.f, 0.f};
+    // input rows are loaded three rows ahead of their MFMAs (a row's 2 x 16 bytes per lane come from HBM: ~1-2 us under load, a
+    // row's matrix work is 0.75 us); the fence keeps the compiler from sinking the loads back to their use
+    constexpr int NR = TH + 2 * P, AHEAD = 3;
+    f32x4h Bq[NR][2];
+#define HEAD_LOAD(RI)                                                                             \
+    do {                                                                                          \
+        const int r_ = y0 - P + (RI);                                                             \
+        const unsigned off_ = (xin && r_ >= 0 && r_ < H) ? (unsigned)((r_ * W + xs) * 32 + 4 * kq) * 4u : 0x80000000u; \
+        Bq[RI][0] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_, 0, 0)); \
+        Bq[RI][1] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_, 64, 0)); \
+    } while (0)
+#pragma unroll
+    for (int ri = 0; ri < AHEAD; ++ri) HEAD_LOAD(ri);
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+        if (ri + AHEAD < NR) HEAD_LOAD(ri + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yi = ri - ky;                    // output row (relative) this input row contributes to through tap ky
+            if (yi < 0 || yi >= TH) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[yi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ky][0][j], Bq[ri][0][j], acc[yi], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[yi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ky][1][j], Bq[ri][1][j], acc[yi], 0, 0, 0);
+        }
+    }
+#undef HEAD_LOAD
+    // T tile -> LDS in two passes of 8 rows (32 KB: four workgroups per CU): [row][column 64][16 slots]; lane holds slots
+    // 4 kq .. 4 kq + 3 of column 16 wave + n16
+    f32x4h *T4 = reinterpret_cast<f32x4h *>(smem);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TH / 2; ++i) T4[(i * 64 + 16 * wave + n16) * 4 + kq] = acc[half * (TH / 2) + i];
+        __syncthreads();
+        for (int idx = tid; idx < (TH / 2) * TWO; idx += 256) {
+            const int yi = idx / TWO, xo = idx - yi * TWO;
+            const int ox = tx * TWO + xo, oy = y0 + half * (TH / 2) + yi;
+            if (ox >= W || oy >= H) continue;
+            const float *t = smem + (yi * 64 + xo) * 16;
+            float u = b0, v = b1;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                u += t[kx * 16 + kx];
+                v += t[kx * 16 + 8 + kx];
+            }
+            const size_t pix = (size_t)(b * H + oy) * W + ox;
+            if (res4) {
+                const f32x4h rr = *reinterpret_cast<const f32x4h *>(res4 + pix * 4);
+                u += rr[0];
+                v += rr[1];
+            }
+            *reinterpret_cast<f32x4h *>(out4 + pix * 4) = f32x4h{u, v, 0.f, 0.f};
+        }
+    }
+}
+
 template <int K>
 static int launch_head_t(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                          hipStream_t st)
@@ -180,6 +285,17 @@ static int launch_head_t(const float *x, const float *w, float b0, float b1, con
     const int nblk = cdiv(W, 16) * cdiv(H, 16) * B;
     // Kernel choice per IMAGE size, never per batch: a pair's flow must not depend on its batch mates (the four-row kernel sums
     // in a different order than the two one-pixel variants, which produce the same bits as each other).
+    // 7 x 7 heads on images of at least 256 x 256: the matrix-core formulation (per image, never per batch)
+    if (K == 7 && (long)H * W >= 256 * 256 && (long)H * W * 32 * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536 * 8)) {
+        constexpr int TWO = 64 - 2 * (K / 2);
+        constexpr int THM = 8;
+        const size_t ldsm = (size_t)(THM / 2) * 64 * 16 * sizeof(float);
+        static LdsAttr attr_m;
+        if (int rc = ensure_dyn_lds(attr_m, reinterpret_cast<const void *>(conv_head_mfma_kernel<K, THM>), (int)ldsm)) return rc;
+        hipLaunchKernelGGL((conv_head_mfma_kernel<K, THM>), dim3(cdiv(W, TWO) * cdiv(H, THM) * B), dim3(256), ldsm, st, x, w, b0, b1, res4, out4, B, H, W);
+        PIV_CHECK_HIP(hipGetLastError());
+        return PIVLFN_OK;
+    }
     if ((long)H * W >= 512 * 512 && !(PIV_KNOB(1) & 8192)) {
         constexpr int PW4 = 32 + K - 1;
         hipLaunchKernelGGL((conv_head4_kernel<K>), dim3(cdiv(W, 32) * cdiv(H, 32) * B), dim3(256), (size_t)PW4 * PW4 * 8 * sizeof(float), st,
@@ -195,7 +311,7 @@ static int launch_head_t(const float *x, const float *w, float b0, float b1, con
     return PIVLFN_OK;
 }
 
-// w: device, [k*k][8][4][2] = (tap, channel quad, channel-in-quad, output)
+// w: device, [k*k][8][4][2] = (tap, channel quad, channel-in-quad, output), then [k][2][64][4] = the matrix-core head's A fragments
 int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                      int k, hipStream_t st)
 {

@@ -223,12 +223,21 @@ static int pack_head(pivlfn_net *net, const TMap &m, const std::string &name, in
     const pivlfn_tensor *w = find(m, name + ".weight", 2, 32, k, k, 4);
     const pivlfn_tensor *b = find(m, name + ".bias", 2, 0, 0, 0, 1);
     if (!w || !b) return PIVLFN_ERR_WEIGHTS;
-    std::vector<float> h((size_t)k * k * 64);
+    // [k*k][8][4][2] for the vector kernels, followed by the A fragments of the matrix-core head (conv_head_mfma_kernel):
+    // [ky][half h][lane 64][4]: lane = slot n (= 8 o + kx) + 16 kq, element j multiplies channel 16 h + 4 kq + j (zero for kx >= k)
+    std::vector<float> h((size_t)k * k * 64 + (size_t)k * 2 * 64 * 4, 0.f);
     for (int t = 0; t < k * k; ++t)
         for (int q = 0; q < 8; ++q)
             for (int o = 0; o < 2; ++o)
                 for (int j = 0; j < 4; ++j)
                     h[(((size_t)t * 8 + q) * 4 + j) * 2 + o] = w->data[((size_t)o * 32 + 4 * q + j) * k * k + t];
+    for (int ky = 0; ky < k; ++ky)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = lane & 15, kq = lane >> 4, o = n >> 3, kx = n & 7, c = 16 * hh + 4 * kq + j;
+                    if (kx < k) h[(size_t)k * k * 64 + (((size_t)ky * 2 + hh) * 64 + lane) * 4 + j] = w->data[((size_t)o * 32 + c) * k * k + ky * k + kx];
+                }
     bias[0] = b->data[0];
     bias[1] = b->data[1];
     return upload(net, h, dev);

@@ -101,7 +101,7 @@ def test_flow_head_kernel_matches_torch(k, dev):
     w = torch.randn(2, 32, k, k, generator=g) / (32 * k * k) ** 0.5
     b = torch.randn(2, generator=g) * 0.1
     conv = Conv(w, b)
-    for (B, H, W) in [(1, 16, 16), (2, 37, 53), (1, 3, 70)]:
+    for (B, H, W) in [(1, 16, 16), (2, 37, 53), (1, 3, 70)] + ([(1, 256, 300), (2, 260, 257)] if k == 7 else []):      # >= 256 x 256: the matrix-core head
         x = torch.randn(B, 32, H, W, generator=g)
         res = torch.randn(B, 2, H, W, generator=g)
         want = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2) + res.double()

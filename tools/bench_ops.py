@@ -255,7 +255,8 @@ def bench_conv_stamps(args):
 
 
 def bench_head(args):
-    """The 32 -> 2 k x k flow heads (conv_M.6 / conv_S.6) at the fine levels: knob bit 8192 = one pixel per lane (old), 0 = shipped."""
+    """The 32 -> 2 k x k flow heads (conv_M.6 / conv_S.6) at the fine levels: knob 524288 + 8192 = one pixel per lane (round 1),
+    524288 = four rows per lane (round 2), 0 = shipped (7 x 7 on >= 256 x 256 images: the matrix-core formulation)."""
     import ctypes
     lib = _toolslib.load()
     dev = torch.device("cuda:0")
@@ -270,7 +271,7 @@ def bench_head(args):
         x = torch.randn(B, n, n, 32, device=dev)
         res = torch.randn(B, n, n, 4, device=dev)
         outs = {}
-        for v in (8192, 0):
+        for v in (524288 + 8192, 524288, 0):
             y = torch.empty(B, n, n, 4, device=dev)
             outs[v] = y
 
@@ -282,7 +283,7 @@ def bench_head(args):
             print(f"{name} B={B} {n}x{n} knob {v}: min {tmin:8.1f} us  med {tmed:8.1f} us  {flop / tmin / 1e6:6.1f} TFLOP/s", flush=True)
         want = torch.nn.functional.conv2d(x[:1].permute(0, 3, 1, 2).double().cpu(), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
         want = want + res[:1, ..., :2].double().cpu()
-        for v in (8192, 0):
+        for v in (524288 + 8192, 524288, 0):
             err = (outs[v][:1, ..., :2].double().cpu() - want).abs().max().item() / want.abs().max().item()
             pad = outs[v][..., 2:].abs().max().item()
             print(f"    knob {v}: max rel err vs float64 conv {err:.2e}, padding lanes max {pad:.1e}")
