@@ -42,6 +42,7 @@ def test_config0_run_py_hui_256_pair(tmp_path, dev):
     """`run.py --model hui -p` on 256x256 pairs: one synthetic particle pair and the reference's own demo pair
     (tests/golden/DNS_turbulence_img{1,2}.tif, grey TIFFs) -> .flo files against the oracle's estimate() on the CPU."""
     import PIL.Image
+    import run as runpy
     d = tmp_path / "pairs"
     d.mkdir()
     a, b, _ = synth.particle_pair(256, 256, 4242)
@@ -71,6 +72,7 @@ def test_config0_run_py_brightness_contrast(tmp_path, dev):
     <prefix>_<BBB>_<CCC>_<suffix>_out.flo, equal to Inference.parser on PIL images enhanced the way the reference does."""
     import PIL.Image
     import PIL.ImageEnhance
+    import run as runpy
     seq = tmp_path / "seq"
     seq.mkdir()
     frames = []
