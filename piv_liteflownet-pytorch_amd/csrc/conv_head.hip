@@ -229,15 +229,18 @@ __global__ __launch_bounds__(256) void conv_head_mfma_kernel(const float *__rest
     for (int ri = 0; ri < NR; ++ri) {
         if (ri + AHEAD < NR) HEAD_LOAD(ri + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
+        // tap ky of input row ri goes to output row ri - ky: consecutive MFMAs target different accumulators (the instruction's
+        // dependent latency is 40 cycles against 32 of issue); per accumulator the order stays (row, half, j)
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int yi = ri - ky;                    // output row (relative) this input row contributes to through tap ky
-            if (yi < 0 || yi >= TH) continue;
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[yi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ky][0][j], Bq[ri][0][j], acc[yi], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[yi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ky][1][j], Bq[ri][1][j], acc[yi], 0, 0, 0);
-        }
+                for (int ky = 0; ky < K; ++ky) {
+                    const int yi = ri - ky;
+                    if (yi < 0 || yi >= TH) continue;
+                    acc[yi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ky][h][j], Bq[ri][h][j], acc[yi], 0, 0, 0);
+                }
     }
 #undef HEAD_LOAD
     // T tile -> LDS in two passes of 8 rows (32 KB: four workgroups per CU): [row][column 64][16 slots]; lane holds slots
@@ -269,6 +272,121 @@ __global__ __launch_bounds__(256) void conv_head_mfma_kernel(const float *__rest
             *reinterpret_cast<f32x4h *>(out4 + pix * 4) = f32x4h{u, v, 0.f, 0.f};
         }
     }
+}
+
+// ---- the same structure for Regularization's (7 x 1) distance convolution, 32 -> 49 channels (conv_dist_R.0 of levels 1 and 2,
+// /root/reference/src/models.py:253-257): four blocks of 16 output channels, one per wave, 16 columns x TH rows per workgroup.  The
+// direct kernel pads 49 channels to two 32-wide blocks and stages a 22-row patch through LDS per 8 input channels; here every
+// wave streams its 16 columns' rows once from global memory (the four waves of a workgroup read the same bytes: L1 hits) against
+// 14 register-resident weight fragments, with no LDS and no barrier, and stores 16-byte channel quads straight from the
+// accumulator layout.  No activation (the reference has none between the two halves of the separable pair).
+template <int TH>
+__global__ __launch_bounds__(256) void conv_col7_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ wf,
+                                                        const float *__restrict__ bias, float *__restrict__ out, int out_stride,
+                                                        int cout_store, int single48, int B, int H, int W)
+{
+    constexpr int K = 7, P = 3, NR = TH + 2 * P, AHEAD = 3;
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + TH - 1) / TH;
+    int bid = xcd_remap(blockIdx.x, tiles_x * tiles_y * B);
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y0 = ty * TH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int blk = __builtin_amdgcn_readfirstlane(tid >> 6);        // 16-channel output block of this wave
+    const int n16 = lane & 15, kq = lane >> 4;
+    f32x4h A[K][2];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) A[ky][h] = *reinterpret_cast<const f32x4h *>(wf + (((blk * K + ky) * 2 + h) * 64 + lane) * 4);
+    const size_t img = (size_t)H * W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)b * img * x_stride), 0,
+                                                                          (unsigned)(((img - 1) * x_stride + 32) * sizeof(float)), 0x00020000);
+    const int xs = tx * 16 + n16;
+    const bool xin = xs < W;
+    f32x4h acc[TH];
+#pragma unroll
+    for (int i = 0; i < TH; ++i) acc[i] = f32x4h{0.f, 0.f, 0.f, 0.f};
+    f32x4h Bq[NR][2];
+#define COL_LOAD(RI)                                                                              \
+    do {                                                                                          \
+        const int r_ = y0 - P + (RI);                                                             \
+        const unsigned off_ = (xin && r_ >= 0 && r_ < H) ? (unsigned)((r_ * W + xs) * x_stride + 4 * kq) * 4u : 0x80000000u; \
+        Bq[RI][0] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_, 0, 0)); \
+        Bq[RI][1] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_, 64, 0)); \
+    } while (0)
+#pragma unroll
+    for (int ri = 0; ri < AHEAD; ++ri) COL_LOAD(ri);
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+        if (ri + AHEAD < NR) COL_LOAD(ri + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk == 3 && single48) {
+            // 49 output channels = three 16-channel blocks + ONE channel: a fourth MFMA block would spend 15 of its 16 rows on
+            // padding.  The fourth wave takes channel 48 on the vector unit instead: its fragment registers hold that channel's
+            // weights (replicated over the slots at pack time), every lane multiplies its 8 channels of the row, the four
+            // channel groups of a pixel are added across lanes at the end.  56 fused multiply-adds per input row where the
+            // matrix version issues 56 MFMAs of 32 cycles.
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int yi = ri - ky;
+                if (yi < 0 || yi >= TH) continue;
+                float e = acc[yi][0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e = fmaf(A[ky][0][j], Bq[ri][0][j], e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e = fmaf(A[ky][1][j], Bq[ri][1][j], e);
+                acc[yi][0] = e;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ky = 0; ky < K; ++ky) {       // consecutive MFMAs target different accumulators; per accumulator: (row, half, j)
+                        const int yi = ri - ky;
+                        if (yi < 0 || yi >= TH) continue;
+                        acc[yi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ky][h][j], Bq[ri][h][j], acc[yi], 0, 0, 0);
+                    }
+        }
+    }
+#undef COL_LOAD
+    if (blk == 3 && single48) {       // channel groups kq = 0..3 of a pixel live in lanes l, l+16, l+32, l+48: add them (fixed order)
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            float e = acc[i][0];
+            e = e + __shfl_xor(e, 16);
+            e = e + __shfl_xor(e, 32);
+            acc[i] = f32x4h{e, 0.f, 0.f, 0.f};
+        }
+    }
+    // lane holds output channels 16 blk + 4 kq .. + 3 of column xs for every row: one 16-byte store per row
+    const int ch = 16 * blk + 4 * kq;
+    if (xin && ch < cout_store) {
+        const f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            const int oy = y0 + i;
+            if (oy < H) *reinterpret_cast<f32x4h *>(out + ((size_t)(b * H + oy) * W + xs) * out_stride + ch) = acc[i] + b4;
+        }
+    }
+}
+
+// wf: [4 blocks][7][2][64][4] fragments (net.hip pack_conv), bias: [64]; single48: the layer has 49 output channels and block 3 of
+// wf holds channel 48's weights replicated over the slots (vector path of the fourth wave)
+int launch_conv_col7(const float *x, int x_stride, const float *wf, const float *bias, float *out, int out_stride, int cout_store,
+                     int single48, int B, int H, int W, hipStream_t st)
+{
+    PIV_REQUIRE(x && wf && bias && out && B > 0 && H > 0 && W > 0, "conv_col7: bad arguments");
+    PIV_REQUIRE(x_stride % 4 == 0 && out_stride % 4 == 0 && cout_store % 4 == 0 && cout_store <= 64 && cout_store <= out_stride, "conv_col7: bad strides");
+    PIV_REQUIRE((long)H * W * x_stride * 4 < (1L << 31), "conv_col7: image exceeds 2 GiB");
+    constexpr int TH = 16;
+    hipLaunchKernelGGL((conv_col7_kernel<TH>), dim3(cdiv(W, 16) * cdiv(H, TH) * B), dim3(256), 0, st, x, x_stride, wf, bias, out, out_stride, cout_store, single48, B, H, W);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
 }
 
 template <int K>

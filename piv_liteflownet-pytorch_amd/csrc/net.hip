@@ -36,6 +36,7 @@ struct ConvW {
     int nchunk_x = 0;
     float scale_x = 1.f;           // 2^-k undoing the weight scale of wpk_x
     void *wtail_x = nullptr;       // 3 x 3 layers whose staged channels end in a 4-lane tail: that chunk with taps folded into K
+    float *wpk_c = nullptr;        // (7 x 1) layers from 32 channels: A fragments of conv_col7_kernel, [4][7][2][64][4]
     float *wpk_w = nullptr;        // 3 x 3 layers: Winograd-domain weights G g G^T in fragment order (conv_wino.hip)
     int nchunk_w = 0;
 };
@@ -168,6 +169,20 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         net->allocs.push_back(d);
         PIV_CHECK_HIP(hipMemcpy(d, ph.data(), ph.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         out->wpk_h = d;
+    }
+    if (kh == 7 && kw == 1 && cin == 32 && cout <= 64 && segs.size() == 1 && segs[0].cload == 32) {   // conv_dist_R.0 of levels 1 and 2
+        std::vector<float> pc((size_t)4 * 7 * 2 * 64 * 4, 0.f);
+        for (int blk = 0; blk < 4; ++blk)
+            for (int ky = 0; ky < 7; ++ky)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            // 49 channels: block 3 = channel 48 replicated over the slots (the kernel's fourth wave takes it on the vector unit)
+                            const int o = (cout == 49 && blk == 3) ? 48 : 16 * blk + (lane & 15), c = 16 * hh + 4 * (lane >> 4) + j;
+                            if (o < cout) pc[((((size_t)blk * 7 + ky) * 2 + hh) * 64 + lane) * 4 + j] = w->data[((size_t)o * 32 + c) * 7 + ky];
+                        }
+        rc = upload(net, pc, &out->wpk_c);
+        if (rc) return rc;
     }
     if (kh == 3 && kw == 3) {      // 3 x 3: the Winograd-domain packing (used by the stride-1 call sites)
         std::vector<int> cr, cl, co;
@@ -447,6 +462,10 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
     p.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
     p.nchunk = c->cw.nchunk; p.tail = c->cw.tail; p.lrelu = leaky;
     p.scratch = c->scratch; p.scratch_floats = KSPLIT_FLOATS;
+    // the (7 x 1) distance convolution on >= 256 x 256 images: the kernel pivlfn_forward uses for it in the fp32 mode
+    if (c->cw.wpk_c && !res && !leaky && stride == 1 && pad_y == 3 && pad_x == 0 && (long)H * W >= 256 * 256 && p.cout_store % 4 == 0 &&
+        (long)H * W * x_stride * 4 < (1L << 31))
+        return launch_conv_col7(x, x_stride, c->cw.wpk_c, c->cw.bias, y, y_stride, p.cout_store, c->cw.cout == 49, B, H, W, st);
     return launch_conv(p, st);
 }
 
@@ -564,6 +583,11 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         q.scratch_floats = KSPLIT_FLOATS * B;
         return launch_conv_x(q, st);
     }
+    // fp32 mode: the (7 x 1) distance convolution of levels 1 and 2 on its streaming matrix-core kernel (per image: >= 256 x 256)
+    if (t_precision == 0 && !res && cw.wpk_c && cw.KH == 7 && cw.KW == 1 && S == 1 && padY == 3 && padX == 0 && !lrelu &&
+        segs.size() == 1 && segs.begin()->cload == 32 && (long)Ho * Wo >= 256 * 256 && cout_store % 4 == 0 &&
+        (long)H * W * segs.begin()->stride * 4 < (1L << 31) && cw.cout_pad <= 64)
+        return launch_conv_col7(segs.begin()->ptr, segs.begin()->stride, cw.wpk_c, cw.bias, out, out_stride, cout_store, cw.cout == 49, B, H, W, st);
     // fp32 mode: the 3 x 3 / stride 1 layers by Winograd F(2x2, 3x3) on the fp32 matrix instruction (conv_wino.hip) from a
     // 64 x 64 grid per image up (a 32 x 32 grid is 32 workgroups with the whole K loop each: the split-K direct kernel is faster);
     // the bound is per image, never a function of the batch

@@ -57,6 +57,8 @@ CASES = [
     (64, 32, 1, 1, 1, (0, 0), 32, 32, 1),         # NetC_ext
     (128, 96, 1, 1, 1, (0, 0), 17, 23, 1),        # moduleFeat
     (49, 32, 7, 1, 1, (3, 0), 32, 40, 1),         # conv_dist_R.0 separable
+    (49, 32, 7, 1, 1, (3, 0), 256, 272, 1),       # conv_dist_R.0 at >= 256 x 256: the streaming matrix-core kernel
+    (49, 32, 7, 1, 1, (3, 0), 300, 261, 2),       # ragged, batch 2
     (49, 49, 1, 7, 1, (0, 3), 32, 40, 1),         # conv_dist_R.1
     (25, 25, 1, 5, 1, (0, 2), 16, 32, 1),
     (9, 32, 3, 3, 1, (1, 1), 8, 8, 3),            # conv_dist_R level 5/6
