@@ -215,6 +215,39 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
         const int t_ = bo0; bo0 = bo1; bo1 = bo2; bo2 = t_;                                       \
     } while (0)
 
+// NBW = 2 with ONE weight set: the two channel blocks are multiplied one after the other (16 MFMAs each) and a block's registers
+// receive the next chunk's fragments as soon as its MFMAs are issued -- half a step of latency cover instead of a whole one, but
+// 32 registers less than two sets, which is what lets 8 accumulators + two channel blocks fit two workgroups per CU without spills.
+#define WINO_MFMA_NW(V, NW, MB_)                                                                  \
+    do {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            _Pragma("unroll") for (int jp = 0; jp < 4; ++jp)                                      \
+                acc[jp][MB_][NW] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[NW][jp][j], V[jp][j], acc[jp][MB_][NW], 0, 0, 0); \
+    } while (0)
+#define WINO_LOADW_NW(NW, CH)                                                                     \
+    do {                                                                                          \
+        const float *w_ = wbase + (size_t)(CH)*wchunk + (NW)*4096 + lane * 4;                     \
+        _Pragma("unroll") for (int jp = 0; jp < 4; ++jp) wA[NW][jp] = *reinterpret_cast<const f32x4 *>(w_ + jp * 256); \
+    } while (0)
+#define WINO_STEP2(VC, VN, CH)                                                                    \
+    do {                                                                                          \
+        const int nx_ = (CH) + 1 < p.nchunk ? (CH) + 1 : (CH);                                    \
+        WINO_LOADP(pr);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WINO_MFMA_NW(VC, 0, 0);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WINO_LOADW_NW(0, nx_);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WINO_MFMA_NW(VC, 1, 0);                                                                   \
+        WINO_READ(raw, bo1, 0);                                                                   \
+        WINO_XFORM(VN, raw);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WINO_LOADW_NW(1, nx_);                                                                    \
+        WINO_COMMIT(pr, bo2);                                                                     \
+        __syncthreads();                                                                          \
+        const int t_ = bo0; bo0 = bo1; bo1 = bo2; bo2 = t_;                                       \
+    } while (0)
+
     // Software pipeline over three patch buffers.  The step of chunk c multiplies chunk c; the patch of chunk c + 2 is in flight
     // (global -> registers) during it and committed to LDS at its end, so after the barrier that closes step c - 1 the image of
     // chunk c + 1 is already readable: the first block's transform of chunk c + 1 is computed inside step c, under the matrix
@@ -235,11 +268,19 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     WINO_READ(raw, bo0, 0);
     WINO_XFORM(vA, raw);
     int chunk = 0;
-    for (; chunk + 1 < p.nchunk; chunk += 2) {
-        WINO_STEP(wA, vA, wB, vB, chunk);
-        WINO_STEP(wB, vB, wA, vA, chunk + 1);
+    if constexpr (MB == 1 && NBW == 2) {
+        for (; chunk + 1 < p.nchunk; chunk += 2) {
+            WINO_STEP2(vA, vB, chunk);
+            WINO_STEP2(vB, vA, chunk + 1);
+        }
+        if (chunk < p.nchunk) WINO_STEP2(vA, vB, chunk);
+    } else {
+        for (; chunk + 1 < p.nchunk; chunk += 2) {
+            WINO_STEP(wA, vA, wB, vB, chunk);
+            WINO_STEP(wB, vB, wA, vA, chunk + 1);
+        }
+        if (chunk < p.nchunk) WINO_STEP(wA, vA, wB, vB, chunk);
     }
-    if (chunk < p.nchunk) WINO_STEP(wA, vA, wB, vB, chunk);
 #undef WINO_LOADP
 #undef WINO_LOADW
 #undef WINO_COMMIT
@@ -247,6 +288,9 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 #undef WINO_XFORM
 #undef WINO_MFMA
 #undef WINO_STEP
+#undef WINO_STEP2
+#undef WINO_MFMA_NW
+#undef WINO_LOADW_NW
 
     // ---- output transform.  acc[jp][mb][nw][4 rg + e] = M[(wave, jp)][cout 32 (nb0 + nw) + 8 rg + 4 g + e][tile n of block mb]
     // column half (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; row half across waves: Y[0] = R_0 + R_1 + R_2, Y[1] = R_1 - R_2 - R_3
@@ -374,11 +418,12 @@ int launch_conv_w(const ConvParamsW &p_in, hipStream_t st)
     const int force = PIV_KNOB(14);
     if (force == 22 && nb % 2 == 0) return launch_w<2, 2>(p, st);
     if (force == 14 && nb % 4 == 0) return launch_w<1, 4>(p, st);
-    if (force == 12 && nb % 2 == 0) return launch_w<1, 2>(p, st);
-    if (force == 21) mb = 2;
+    if (force == 21) return launch_w<2, 1>(p, st);
     if (force == 11) mb = 1;
 #endif
-    (void)sp1;
+    // two channel blocks per wave (half the transform work per MFMA, one weight set) wherever the layer has an even number of
+    // 32-channel blocks: -4...-5 % against 16-row tiles with one block per wave on every such layer of levels 1 and 2
+    if (nb % 2 == 0 && sp1 * (nb / 2) >= 256) return launch_w<1, 2>(p, st);
     if (mb == 2) return launch_w<2, 1>(p, st);
     return launch_w<1, 1>(p, st);
 }
