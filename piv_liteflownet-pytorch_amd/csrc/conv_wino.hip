@@ -29,6 +29,28 @@ namespace pivlfn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// a - b on two register pairs: v_pk_add_f32 with the second operand negated (exactly the two fp32 subtractions)
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
+{
+    f32x2 lo, hi;
+    const f32x2 al = __builtin_shufflevector(a, a, 0, 1), ah = __builtin_shufflevector(a, a, 2, 3);
+    const f32x2 bl = __builtin_shufflevector(b, b, 0, 1), bh = __builtin_shufflevector(b, b, 2, 3);
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(al), "v"(bl));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ah), "v"(bh));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+// a + s * b with s = (+-1, +-1): two v_pk_fma_f32 (the product is exact, so this is the fp32 sum or difference)
+__device__ __forceinline__ f32x4 pk_fma4(f32x2 s, f32x4 b, f32x4 a)
+{
+    f32x2 lo, hi;
+    const f32x2 al = __builtin_shufflevector(a, a, 0, 1), ah = __builtin_shufflevector(a, a, 2, 3);
+    const f32x2 bl = __builtin_shufflevector(b, b, 0, 1), bh = __builtin_shufflevector(b, b, 2, 3);
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(s), "v"(bl), "v"(al));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(s), "v"(bh), "v"(ah));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 
 constexpr int WPW = 18;      // patch width in pixels: 8 tiles x 2 + 2
 // LDS image of one chunk's patch.  Every operand read is one 16-byte quad per lane at pixel (2 ty + r, 2 tx + c) of the lane's
@@ -97,6 +119,7 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sb = wave == 1 ? 1.f : -1.f;
+    const f32x2 sb2 = {sb, sb};
     int abase[MB], bbase[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -177,15 +200,17 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
             RAW[4 + c] = smem4[(BOFF) + bbase[MB_] + ((c >> 1) + (c & 1) * 9) * WPIXQ];           \
         }                                                                                         \
     } while (0)
-// V = (B^T d B)[wave][0..3]
+// V = (B^T d B)[wave][0..3], all of it as packed fp32 instructions on channel pairs (8 v_pk_fma_f32 for the row combination with
+// the wave's sign, 8 v_pk_add_f32 for the columns, the differences through the negate modifiers): left to the compiler the
+// differences become two v_sub_f32 per pair.  Same fp32 sums and differences, same bits.
 #define WINO_XFORM(V, RAW)                                                                        \
     do {                                                                                          \
         f32x4 tt_[4];                                                                             \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) tt_[c] = RAW[c] + sb * RAW[4 + c];          \
-        V[0] = tt_[0] - tt_[2];                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) tt_[c] = pk_fma4(sb2, RAW[4 + c], RAW[c]);  \
+        V[0] = pk_sub4(tt_[0], tt_[2]);                                                           \
         V[1] = tt_[1] + tt_[2];                                                                   \
-        V[2] = tt_[2] - tt_[1];                                                                   \
-        V[3] = tt_[1] - tt_[3];                                                                   \
+        V[2] = pk_sub4(tt_[2], tt_[1]);                                                           \
+        V[3] = pk_sub4(tt_[1], tt_[3]);                                                           \
     } while (0)
 #define WINO_MFMA(V, WC, MB_)                                                                     \
     do {                                                                                          \
@@ -383,7 +408,10 @@ template <int MB, int NBW>
 static int launch_w(const ConvParamsW &p, hipStream_t st)
 {
     constexpr int PH = 8 * MB + 2;
-    const size_t lds = std::max<size_t>((size_t)MB * NBW * 32768, (size_t)3 * (PH * WROWQ + WPIXQ) * 16);
+    size_t lds = std::max<size_t>((size_t)MB * NBW * 32768, (size_t)3 * (PH * WROWQ + WPIXQ) * 16);
+#ifdef PIVLFN_TOOLS
+    if (PIV_KNOB(1) & 1048576) lds = 96 * 1024;      // measurement: one workgroup per CU (tools/bench_wino.py --masks 65536)
+#endif
     static LdsAttr attr;
     if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_wino_kernel<MB, NBW>), (int)lds)) return rc;
     const long blocks = (long)p.B * cdiv(p.H, 8 * MB) * cdiv(p.W, 16) * (p.cout_pad / (32 * NBW));

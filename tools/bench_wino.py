@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--layers", default="")
     ap.add_argument("--ab", default="", help="path of a second build of libpivlfn.so: its Winograd kernel is timed beside the current one (interleaved rounds)")
-    ap.add_argument("--masks", default="", help="tools build only: ablation masks of the Winograd kernel (1 no MFMAs, 2 no weight loads, 4 no patch loads, 8 no epilogue)")
+    ap.add_argument("--masks", default="", help="tools build only: per-variant masks of the Winograd kernel: (m >> 8) & 255 = forced tile shape (11, 21, 22, 14), 65536 = one workgroup per CU")
     a = ap.parse_args()
     lib = _lib.load()
     if a.masks:
@@ -76,10 +76,12 @@ def main():
                 for m in [int(v) for v in a.masks.split(",")]:
                     def wm(m=m):
                         lib.pivlfn_tune(13, m & 255)
-                        lib.pivlfn_tune(14, m >> 8)
+                        lib.pivlfn_tune(14, (m >> 8) & 255)
+                        lib.pivlfn_tune(1, 1048576 if m & 65536 else 0)
                         wino()
                         lib.pivlfn_tune(13, 0)
                         lib.pivlfn_tune(14, 0)
+                        lib.pivlfn_tune(1, 0)
                     fns[f"mask{m}"] = wm
             times = {k: [] for k in fns}
             for k in fns:
