@@ -5,7 +5,7 @@ set -e
 OUT=$PWD/gpurun_out/pmc_wino
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc ${PMC:-SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY} GRBM_GUI_ACTIVE \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc ${PMC:-SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY} GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/sq" -- python3 tools/bench_wino.py --levels 1 --layers ${LAYERS:-128x128} --rounds 2 --n 3 ${ARGS:-} > "$OUT/sq.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys
