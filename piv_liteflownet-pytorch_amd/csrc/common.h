@@ -201,7 +201,7 @@ int launch_dwconvT(const float *in, const float *w, float *out, int B, int H, in
 int launch_backwarp_nhwc(const float *in, const float *flow4, float scale, float *out, int B, int H, int W,
                          int C, hipStream_t st);
 int launch_flow_mean(const float *flow4, float *partial, float *mean, int B, int HW, hipStream_t st);
-int launch_reg_prep(const float *img1, const float *img2, const float *flow4, const float *mean, float scale,
+int launch_reg_prep(const float *img1, const float *img2, const float *flow4, float *mean, const float *partial, float scale,
                     float *misc4, int B, int H, int W, hipStream_t st);
 int launch_reg_tail(const float *dist, int dstride, const float *flow4, const float *wx, const float *wy,
                     float bx, float by, int k, float *out4, float *out_nchw, float out_scale,

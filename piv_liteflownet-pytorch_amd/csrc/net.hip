@@ -877,8 +877,8 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         else
             RUN(launch_conv_head(hid, lw.headS, lw.hbS[0], lw.hbS[1], bf.flowM, bf.flowS, B, hh, ww, k, st));
         // ---- Regularization (:274-303); note it takes the RAW NetC feature (:361)
-        RUN(launch_flow_mean(bf.flowS, bf.partial, bf.mean, B, hh * ww, st));
-        RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, sc, bf.misc4, B, hh, ww, st));
+        RUN(launch_flow_mean(bf.flowS, bf.partial, nullptr, B, hh * ww, st));       // partial sums only: reg_prep finishes the mean
+        RUN(launch_reg_prep(im1, im2, bf.flowS, bf.mean, bf.partial, sc, bf.misc4, B, hh, ww, st));
         if (L == 3 || L == 4) { PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0)); side_join.pending &= ~(1u << L); }
         const float *fr = L < 5 ? bf.featR[L] : f1raw;
         const int cfr = L < 5 ? 128 : cf;

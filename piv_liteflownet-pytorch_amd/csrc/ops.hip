@@ -264,40 +264,62 @@ __global__ __launch_bounds__(256) void flow_mean_stage1(const float *__restrict_
     }
 }
 
+// Second stage of the mean: the MEAN_BLOCKS partial sums of image b, tree over one wave's lanes, / HW.  Every workgroup of
+// reg_prep_kernel runs it for itself (64 loads and 6 shuffles: cheaper than the launch a separate one-wave kernel costs in the
+// dependent chain of a level); the one-wave kernel stays for the stand-alone entry point.  Same tree, same bits.
+__device__ __forceinline__ float2 mean_from_partials(const float *__restrict__ partial, int b, int HW, int lane)
+{
+    float2 v = make_float2(partial[((size_t)b * MEAN_BLOCKS + lane) * 2], partial[((size_t)b * MEAN_BLOCKS + lane) * 2 + 1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v.x += __shfl_down(v.x, o);
+        v.y += __shfl_down(v.y, o);
+    }
+    const float2 r = make_float2(0.f + __shfl(v.x, 0), 0.f + __shfl(v.y, 0));      // block_sum2's final "0 + sh[0]" (exact)
+    return make_float2(r.x / (float)HW, r.y / (float)HW);
+}
+
 __global__ __launch_bounds__(64) void flow_mean_stage2(const float *__restrict__ partial, float *__restrict__ mean, int HW)
 {
-    __shared__ float2 sh[1];
-    const int b = blockIdx.x;
-    float2 s = make_float2(partial[((size_t)b * MEAN_BLOCKS + threadIdx.x) * 2], partial[((size_t)b * MEAN_BLOCKS + threadIdx.x) * 2 + 1]);
-    const float2 r = block_sum2(s, sh);
+    const float2 m = mean_from_partials(partial, blockIdx.x, HW, threadIdx.x);
     if (threadIdx.x == 0) {
-        mean[b * 2 + 0] = r.x / (float)HW;
-        mean[b * 2 + 1] = r.y / (float)HW;
+        mean[blockIdx.x * 2 + 0] = m.x;
+        mean[blockIdx.x * 2 + 1] = m.y;
     }
 }
 
 int launch_flow_mean(const float *flow4, float *partial, float *mean, int B, int HW, hipStream_t st)
 {
     hipLaunchKernelGGL(flow_mean_stage1, dim3(MEAN_BLOCKS, B), dim3(256), 0, st, flow4, partial, HW);
-    hipLaunchKernelGGL(flow_mean_stage2, dim3(B), dim3(64), 0, st, partial, mean, HW);
+    if (mean) hipLaunchKernelGGL(flow_mean_stage2, dim3(B), dim3(64), 0, st, partial, mean, HW);      // mean == nullptr: the consumer reduces the partials itself
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
 
 // ---- Regularization front (:275-277): rm = flow - mean; norm = ||img1 - backwarp(img2, flow*scale)||_2 ------------
+// grid = (blocks per image, B); `partial` != nullptr: the mean is formed here from flow_mean_stage1's partial sums (and written to
+// `mean` by the first workgroup of every image, for callers that read it back); else `mean` is read.
 __global__ __launch_bounds__(256) void reg_prep_kernel(const f32x4 *__restrict__ img1, const f32x4 *__restrict__ img2,
-                                                       const f32x4 *__restrict__ flow4, const float *__restrict__ mean,
-                                                       float scale, f32x4 *__restrict__ misc4, int B, int H, int W)
+                                                       const f32x4 *__restrict__ flow4, float *__restrict__ mean,
+                                                       const float *__restrict__ partial,
+                                                       float scale, f32x4 *__restrict__ misc4, int H, int W)
 {
-    const unsigned total = (unsigned)B * H * W;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const int x = (int)(i % (unsigned)W);
-        const unsigned r = i / (unsigned)W;
-        const int y = (int)(r % (unsigned)H);
-        const int b = (int)(r / (unsigned)H);
+    const int b = blockIdx.y;
+    const unsigned HW = (unsigned)H * W;
+    float2 m;
+    if (partial) {
+        m = mean_from_partials(partial, b, (int)HW, threadIdx.x & 63);        // every wave for itself: no barrier
+        if (blockIdx.x == 0 && threadIdx.x == 0) { mean[b * 2 + 0] = m.x; mean[b * 2 + 1] = m.y; }
+    } else {
+        m = make_float2(mean[b * 2 + 0], mean[b * 2 + 1]);
+    }
+    const f32x4 *base = img2 + (size_t)b * HW;
+    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < HW; p += gridDim.x * 256u) {
+        const int x = (int)(p % (unsigned)W);
+        const int y = (int)(p / (unsigned)W);
+        const size_t i = (size_t)b * HW + p;
         const f32x4 fl = flow4[i];
         const Taps t = make_taps((float)x + fl[0] * scale, (float)y + fl[1] * scale, H, W);
-        const f32x4 *base = img2 + (size_t)b * H * W;
         f32x4 wv = {0.f, 0.f, 0.f, 0.f};
         if (t.o00 >= 0) wv += t.w00 * base[t.o00];
         if (t.o01 >= 0) wv += t.w01 * base[t.o01];
@@ -306,20 +328,21 @@ __global__ __launch_bounds__(256) void reg_prep_kernel(const f32x4 *__restrict__
         const f32x4 d = img1[i] - wv;
         f32x4 o;
         o[0] = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        o[1] = fl[0] - mean[b * 2 + 0];
-        o[2] = fl[1] - mean[b * 2 + 1];
+        o[1] = fl[0] - m.x;
+        o[2] = fl[1] - m.y;
         o[3] = 0.f;
         misc4[i] = o;
     }
 }
 
-int launch_reg_prep(const float *img1, const float *img2, const float *flow4, const float *mean, float scale,
+int launch_reg_prep(const float *img1, const float *img2, const float *flow4, float *mean, const float *partial, float scale,
                     float *misc4, int B, int H, int W, hipStream_t st)
 {
-    const size_t total = (size_t)B * H * W;
-    hipLaunchKernelGGL(reg_prep_kernel, dim3(grid_for(total)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(img1),
-                       reinterpret_cast<const f32x4 *>(img2), reinterpret_cast<const f32x4 *>(flow4), mean, scale,
-                       reinterpret_cast<f32x4 *>(misc4), B, H, W);
+    const size_t per = (size_t)H * W;
+    const int gx = (int)std::min<size_t>((per + 255) / 256, (size_t)std::max(1, 8192 / B));
+    hipLaunchKernelGGL(reg_prep_kernel, dim3(gx, B), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(img1),
+                       reinterpret_cast<const f32x4 *>(img2), reinterpret_cast<const f32x4 *>(flow4), mean, partial, scale,
+                       reinterpret_cast<f32x4 *>(misc4), H, W);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
