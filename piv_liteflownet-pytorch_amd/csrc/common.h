@@ -172,6 +172,7 @@ struct ConvParamsW {
     int out_stride, cout_store, cout_pad;
     int B, H, W;        // output grid = input grid (3x3, stride 1, pad 1)
     int nchunk, lrelu;
+    unsigned long long *stamps;   // tools build (-DPIVLFN_STAMPS) only: per-workgroup phase times of wave 0 (s_memtime ticks), 8 per workgroup; nullptr in production
 };
 int launch_conv_w(const ConvParamsW &p, hipStream_t st);
 bool conv_wino_supports(int KH, int KW, int S, int padY, int padX);

@@ -41,6 +41,13 @@ __device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ah), "v"(bh));
     return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
+// max(a, b) as the bare instruction (fmaxf adds a canonicalising v_max x, x in front of every operand that came out of inline assembly)
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // a + s * b with s = (+-1, +-1): two v_pk_fma_f32 (the product is exact, so this is the fp32 sum or difference)
 __device__ __forceinline__ f32x4 pk_fma4(f32x2 s, f32x4 b, f32x4 a)
 {
@@ -128,15 +135,10 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
         bbase[mb] = (tyl + (rb >> 1) + (rb & 1) * (PH / 2)) * WROWQ + txl * WPIXQ + g;
     }
 
+    // (no zero initialisation: the first chunk's MFMAs take the constant 0 as their C operand -- 64 or 128 v_mov fewer in a prologue
+    //  whose vector instructions queue behind the co-resident workgroup's MFMAs)
     f32x16 acc[4][MB][NBW];
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nw = 0; nw < NBW; ++nw)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[jp][mb][nw][r] = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // weights of (chunk, nb, wave): 4 planes x 64 lanes x 4 floats, contiguous; the wave's NBW blocks are 4096 floats apart
     const float *wbase = p.wpk + ((size_t)nb0 * 4 + wave) * 1024;
@@ -212,26 +214,26 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
         V[2] = pk_sub4(tt_[2], tt_[1]);                                                           \
         V[3] = pk_sub4(tt_[1], tt_[3]);                                                           \
     } while (0)
-#define WINO_MFMA(V, WC, MB_)                                                                     \
+#define WINO_MFMA(V, WC, MB_, Z)                                                                  \
     do {                                                                                          \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
             _Pragma("unroll") for (int jp = 0; jp < 4; ++jp)                                      \
                 _Pragma("unroll") for (int nw = 0; nw < NBW; ++nw)                                \
-                    acc[jp][MB_][nw] = __builtin_amdgcn_mfma_f32_32x32x2f32(WC[nw][jp][j], V[jp][j], acc[jp][MB_][nw], 0, 0, 0); \
+                    acc[jp][MB_][nw] = __builtin_amdgcn_mfma_f32_32x32x2f32(WC[nw][jp][j], V[jp][j], ((Z) && j == 0) ? zero16 : acc[jp][MB_][nw], 0, 0, 0); \
     } while (0)
 // One chunk: multiply chunk CH with (WC, VC); put chunk CH + 1's weights (-> WN) and chunk CH + 2's patch (-> pr -> LDS) in flight;
 // compute the first block's transform of chunk CH + 1 (-> VN) under the matrix work.
-#define WINO_STEP(WC, VC, WN, VN, CH)                                                             \
+#define WINO_STEP(WC, VC, WN, VN, CH, Z)                                                           \
     do {                                                                                          \
         WINO_LOADW(WN, (CH) + 1 < p.nchunk ? (CH) + 1 : (CH));                                    \
         WINO_LOADP(pr);                                                                           \
         __builtin_amdgcn_sched_barrier(0);      /* the loads stay in front of the matrix work (the scheduler would sink them to their first use) */ \
-        WINO_MFMA(VC, WC, 0);                                                                     \
+        WINO_MFMA(VC, WC, 0, Z);                                                                  \
         if (MB == 2) {                                                                            \
             f32x4 v1_[4];                                                                         \
             WINO_READ(raw, bo0, MB - 1);                                                          \
             WINO_XFORM(v1_, raw);                                                                 \
-            WINO_MFMA(v1_, WC, MB - 1);                                                           \
+            WINO_MFMA(v1_, WC, MB - 1, Z);                                                        \
         }                                                                                         \
         WINO_READ(raw, bo1, 0);                                                                   \
         WINO_XFORM(VN, raw);                                                                      \
@@ -243,33 +245,49 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 // NBW = 2 with ONE weight set: the two channel blocks are multiplied one after the other (16 MFMAs each) and a block's registers
 // receive the next chunk's fragments as soon as its MFMAs are issued -- half a step of latency cover instead of a whole one, but
 // 32 registers less than two sets, which is what lets 8 accumulators + two channel blocks fit two workgroups per CU without spills.
-#define WINO_MFMA_NW(V, NW, MB_)                                                                  \
+#define WINO_MFMA_NW(V, NW, MB_, Z)                                                               \
     do {                                                                                          \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
             _Pragma("unroll") for (int jp = 0; jp < 4; ++jp)                                      \
-                acc[jp][MB_][NW] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[NW][jp][j], V[jp][j], acc[jp][MB_][NW], 0, 0, 0); \
+                acc[jp][MB_][NW] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[NW][jp][j], V[jp][j], ((Z) && j == 0) ? zero16 : acc[jp][MB_][NW], 0, 0, 0); \
     } while (0)
 #define WINO_LOADW_NW(NW, CH)                                                                     \
     do {                                                                                          \
         const float *w_ = wbase + (size_t)(CH)*wchunk + (NW)*4096 + lane * 4;                     \
         _Pragma("unroll") for (int jp = 0; jp < 4; ++jp) wA[NW][jp] = *reinterpret_cast<const f32x4 *>(w_ + jp * 256); \
     } while (0)
-#define WINO_STEP2(VC, VN, CH)                                                                    \
+#ifdef PIVLFN_STAMPS
+#define WSTAMP(ACC)                                                                               \
+    do {                                                                                          \
+        if (stamp_) {                                                                             \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
+            ACC += now_ - tk_;                                                                    \
+            tk_ = now_;                                                                           \
+        }                                                                                         \
+    } while (0)
+#else
+#define WSTAMP(ACC) do { } while (0)
+#endif
+#define WINO_STEP2(VC, VN, CH, Z)                                                                  \
     do {                                                                                          \
         const int nx_ = (CH) + 1 < p.nchunk ? (CH) + 1 : (CH);                                    \
         WINO_LOADP(pr);                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        WINO_MFMA_NW(VC, 0, 0);                                                                   \
+        WINO_MFMA_NW(VC, 0, 0, Z);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WINO_LOADW_NW(0, nx_);                                                                    \
+        WSTAMP(d_blk0_);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        WINO_MFMA_NW(VC, 1, 0);                                                                   \
+        WINO_MFMA_NW(VC, 1, 0, Z);                                                                 \
         WINO_READ(raw, bo1, 0);                                                                   \
         WINO_XFORM(VN, raw);                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                        \
+        WSTAMP(d_blk1_);                                                                          \
         WINO_LOADW_NW(1, nx_);                                                                    \
         WINO_COMMIT(pr, bo2);                                                                     \
+        WSTAMP(d_commit_);                                                                        \
         __syncthreads();                                                                          \
+        WSTAMP(d_bar_);                                                                           \
         const int t_ = bo0; bo0 = bo1; bo1 = bo2; bo2 = t_;                                       \
     } while (0)
 
@@ -278,6 +296,11 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     // chunk c + 1 is already readable: the first block's transform of chunk c + 1 is computed inside step c, under the matrix
     // work of chunk c, and the first MFMA of a step issues right behind the barrier.  The loop is unrolled twice with the two
     // register sets (weights, first operand) swapping roles: no copies.
+#ifdef PIVLFN_STAMPS
+    const bool stamp_ = p.stamps != nullptr && wave == 0 && blockIdx.x < 8192;
+    unsigned long long tk_ = 0, t_begin_ = 0, d_blk0_ = 0, d_blk1_ = 0, d_commit_ = 0, d_bar_ = 0, d_pro_ = 0;
+    if (stamp_) t_begin_ = tk_ = __builtin_amdgcn_s_memtime();
+#endif
     f32x4 *smem4 = reinterpret_cast<f32x4 *>(smem);
     int bo0 = 0, bo1 = PBUF, bo2 = 2 * PBUF;       // quad offsets of the buffers holding chunks c, c + 1, c + 2
     {   // prologue: the first two patches and the first weights all in flight together (one memory round trip, not two)
@@ -293,18 +316,22 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     WINO_READ(raw, bo0, 0);
     WINO_XFORM(vA, raw);
     int chunk = 0;
+    WSTAMP(d_pro_);
+    // the first chunk is peeled: its MFMAs start the accumulators from the constant 0
     if constexpr (MB == 1 && NBW == 2) {
-        for (; chunk + 1 < p.nchunk; chunk += 2) {
-            WINO_STEP2(vA, vB, chunk);
-            WINO_STEP2(vB, vA, chunk + 1);
+        WINO_STEP2(vA, vB, 0, true);
+        for (chunk = 1; chunk + 1 < p.nchunk; chunk += 2) {
+            WINO_STEP2(vB, vA, chunk, false);
+            WINO_STEP2(vA, vB, chunk + 1, false);
         }
-        if (chunk < p.nchunk) WINO_STEP2(vA, vB, chunk);
+        if (chunk < p.nchunk) WINO_STEP2(vB, vA, chunk, false);
     } else {
-        for (; chunk + 1 < p.nchunk; chunk += 2) {
-            WINO_STEP(wA, vA, wB, vB, chunk);
-            WINO_STEP(wB, vB, wA, vA, chunk + 1);
+        WINO_STEP(wA, vA, wB, vB, 0, true);
+        for (chunk = 1; chunk + 1 < p.nchunk; chunk += 2) {
+            WINO_STEP(wB, vB, wA, vA, chunk, false);
+            WINO_STEP(wA, vA, wB, vB, chunk + 1, false);
         }
-        if (chunk < p.nchunk) WINO_STEP(wA, vA, wB, vB, chunk);
+        if (chunk < p.nchunk) WINO_STEP(wB, vB, wA, vA, chunk, false);
     }
 #undef WINO_LOADP
 #undef WINO_LOADW
@@ -314,9 +341,14 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 #undef WINO_MFMA
 #undef WINO_STEP
 #undef WINO_STEP2
+#undef WSTAMP
 #undef WINO_MFMA_NW
 #undef WINO_LOADW_NW
 
+#ifdef PIVLFN_STAMPS
+    unsigned long long t_loop_end_ = 0;
+    if (stamp_) t_loop_end_ = __builtin_amdgcn_s_memtime();
+#endif
     // ---- output transform.  acc[jp][mb][nw][4 rg + e] = M[(wave, jp)][cout 32 (nb0 + nw) + 8 rg + 4 g + e][tile n of block mb]
     // column half (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; row half across waves: Y[0] = R_0 + R_1 + R_2, Y[1] = R_1 - R_2 - R_3
     f32x4 *xch = reinterpret_cast<f32x4 *>(smem);       // [mb][nw][wave][q][rg][lane]
@@ -331,7 +363,7 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
                 for (int jp = 0; jp < 4; ++jp)
                     m[jp] = f32x4{acc[jp][mb][nw][4 * rg + 0], acc[jp][mb][nw][4 * rg + 1], acc[jp][mb][nw][4 * rg + 2], acc[jp][mb][nw][4 * rg + 3]};
                 xch[((((mb * NBW + nw) * 4 + wave) * 2 + 0) * 4 + rg) * 64 + lane] = (m[0] + m[1]) + m[2];
-                xch[((((mb * NBW + nw) * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = (m[1] - m[2]) - m[3];
+                xch[((((mb * NBW + nw) * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = pk_sub4(pk_sub4(m[1], m[2]), m[3]);
             }
     __syncthreads();
     const int pp = wave >> 1, qq = wave & 1;      // this wave finishes output pixel (pp, qq) of every tile
@@ -351,15 +383,26 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
                 const f32x4 *x = xch + (((mb * NBW + nw) * 4 * 2 + qq) * 4 + rg) * 64 + lane;     // wave i at x[i * 2 * 4 * 64]
                 f32x4 y;
                 if (pp == 0) y = (x[0] + x[1 * 512]) + x[2 * 512];
-                else y = (x[1 * 512] - x[2 * 512]) - x[3 * 512];
+                else y = pk_sub4(pk_sub4(x[1 * 512], x[2 * 512]), x[3 * 512]);
                 y += bias4[rg];
-                if (p.lrelu) {
-                    y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
+                if (p.lrelu) {      // v >= 0 ? v : 0.1 v  ==  max(v, 0.1 v), two instructions per pair of values less than compare + select
+                    const f32x4 t = 0.1f * y;
+                    y[0] = vmax(y[0], t[0]); y[1] = vmax(y[1], t[1]); y[2] = vmax(y[2], t[2]); y[3] = vmax(y[3], t[3]);
                 }
                 if (ok && cb + 8 * rg < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * rg) = y;
             }
         }
     }
+#ifdef PIVLFN_STAMPS
+    if (stamp_ && lane == 0) {
+        const unsigned long long t_end_ = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 8;
+        o[0] = d_pro_; o[1] = d_blk0_; o[2] = d_blk1_; o[3] = d_commit_; o[4] = d_bar_;
+        o[5] = t_end_ - t_loop_end_;      // epilogue
+        o[6] = t_end_ - t_begin_;
+        o[7] = t_begin_;
+    }
+#endif
 }
 
 // OIHW [cout][cin][3][3] -> Winograd-domain weights in MFMA A-fragment order:
@@ -424,6 +467,7 @@ static int launch_w(const ConvParamsW &p, hipStream_t st)
 int launch_conv_w(const ConvParamsW &p_in, hipStream_t st)
 {
     ConvParamsW p = p_in;
+    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only (0 in production)
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.wpk && p.bias && p.out, "conv_wino: bad arguments");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0 && p.out_stride % 4 == 0,
                 "conv_wino: cout_pad=%d cout_store=%d out_stride=%d", p.cout_pad, p.cout_store, p.out_stride);

@@ -19,6 +19,49 @@ from pivlfn import _lib  # noqa: E402
 LAYERS = [(49, 128), (128, 64), (64, 32), (130, 128), (131, 128), (128, 128), (64, 64), (32, 32)]
 
 
+def stamps(a):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _toolslib
+    lib = _toolslib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    layers = [tuple(int(v) for v in s.split("x")) for s in a.layers.split(",")] if a.layers else [(128, 128)]
+    names = ["prologue", "block 0 (+W0 issue)", "block 1 + reads + transform", "W1 issue + commit", "barrier", "epilogue", "whole"]
+    for L in [int(x) for x in a.levels.split(",")]:
+        n = a.size >> (L - 1)
+        for ci, co in layers:
+            g = torch.Generator().manual_seed(ci * 7 + co)
+            w = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).contiguous()
+            b = torch.randn(co, generator=g).contiguous()
+            h = ctypes.c_void_p()
+            _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(h)), "create")
+            xs = -(-ci // 4) * 4
+            x = torch.randn(a.batch, n, n, xs, device=dev)
+            y = torch.empty(a.batch, n, n, co, device=dev)
+            buf = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+            ptr = buf.data_ptr()
+            for one in (0, 1):
+                lib.pivlfn_tune(1, 1048576 if one else 0)
+                for _ in range(3):
+                    _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y.data_ptr(), co, a.batch, n, n, 1, st), "wino")
+                buf.zero_()
+                lib.pivlfn_tune(5, ctypes.c_int32(ptr & 0xFFFFFFFF).value)
+                lib.pivlfn_tune(6, ctypes.c_int32((ptr >> 32) & 0xFFFFFFFF).value)
+                _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y.data_ptr(), co, a.batch, n, n, 1, st), "wino")
+                torch.cuda.synchronize()
+                lib.pivlfn_tune(5, 0)
+                lib.pivlfn_tune(6, 0)
+                lib.pivlfn_tune(1, 0)
+                t = buf.view(-1, 8).cpu().numpy()
+                t = t[t[:, 6] > 0]
+                nch = -(-ci // 8)
+                tot = t[:, 6].mean()
+                print(f"L{L} {ci}->{co} {'one workgroup' if one else 'two workgroups'} per CU: {len(t)} workgroups stamped, {nch} chunks; ticks per workgroup (mean): " +
+                      "  ".join(f"{nm} {t[:, i].mean():.0f} ({100 * t[:, i].mean() / tot:.0f} %)" for i, nm in enumerate(names)), flush=True)
+                print("    per chunk: " + "  ".join(f"{nm} {t[:, i].mean() / nch:.0f}" for i, nm in list(enumerate(names))[1:5]), flush=True)
+            lib.pivlfn_conv_destroy(h)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1024)
@@ -29,8 +72,11 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--ab", default="", help="path of a second build of libpivlfn.so: its Winograd kernel is timed beside the current one (interleaved rounds)")
     ap.add_argument("--masks", default="", help="tools build only: per-variant masks of the Winograd kernel: (m >> 8) & 255 = forced tile shape (11, 21, 22, 14), 65536 = one workgroup per CU")
+    ap.add_argument("--stamps", action="store_true", help="tools build only: phase times of wave 0 of every workgroup (s_memtime ticks) for the two-block shape, at two and at one workgroup per CU")
     a = ap.parse_args()
     lib = _lib.load()
+    if a.stamps:
+        return stamps(a)
     if a.masks:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import _toolslib
