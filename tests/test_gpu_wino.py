@@ -45,6 +45,11 @@ CASES = [
     (128, 386, 8, 8, 1),         # conv_S.0 level-6 width
     (9, 32, 8, 24, 2),           # cout not a multiple of 4: lanes 9..11 zero
     (128, 128, 130, 70, 1),      # several workgroups in both directions, ragged
+    # full-size launches (more workgroups than the chip holds at once, two co-resident per CU), one per tile shape
+    (64, 64, 512, 250, 1),       # two channel blocks per wave (1, 2): 64 x 16 = 1024 workgroups
+    (32, 32, 380, 384, 4),       # 16-row tiles (2, 1): 4 x 24 x 24 = 2304 workgroups
+    (32, 16, 320, 320, 1),       # 8-row tiles, one block (1, 1): 800 workgroups
+    (96, 40, 300, 310, 1),       # odd number of channel blocks, 4-lane tail: (2, 1) x 3 groups
 ]
 
 

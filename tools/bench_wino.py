@@ -123,7 +123,7 @@ def main():
                     def wm(m=m):
                         lib.pivlfn_tune(13, m & 255)
                         lib.pivlfn_tune(14, (m >> 8) & 255)
-                        lib.pivlfn_tune(1, 1048576 if m & 65536 else 0)
+                        lib.pivlfn_tune(1, (m >> 16) << 20)
                         wino()
                         lib.pivlfn_tune(13, 0)
                         lib.pivlfn_tune(14, 0)
@@ -155,10 +155,17 @@ def main():
             if a.masks:
                 direct()
                 diffs = {}
+                first = None
                 for k in fns:
                     y["wino"].fill_(float("nan"))
                     fns[k]()
                     diffs[k] = (y["wino"] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
+                    if first is None:
+                        first = y["wino"].clone()
+                    elif not torch.equal(first, y["wino"]):
+                        bad = (first != y["wino"]).nonzero()
+                        print(f"    {k}: {len(bad)} values differ from the first variant's; first at (b, y, x, c) = {bad[0].tolist()}, last {bad[-1].tolist()}, "
+                              f"max |diff| {(first - y['wino']).abs().max().item():.3e}", flush=True)
                 print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: " + "   ".join(f"{k} min {min(v):8.1f} med {sorted(v)[len(v) // 2]:8.1f} us (diff {diffs[k]:.1e})" for k, v in times.items()), flush=True)
                 lib.pivlfn_conv_destroy(h)
                 continue
