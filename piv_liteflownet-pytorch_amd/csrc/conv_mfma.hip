@@ -29,6 +29,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int PIXP = 12;
+constexpr unsigned C2OOB = 0x80000000u;      // buffer-load offset beyond every descriptor: reads as zero
 
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
@@ -189,7 +190,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
     // this thread's staging slots: patch slot i covers (pixel, quad) = (idx>>1, idx&1), idx = tid + 256*i
     const int npix2 = PH * PW * 2;
     const int nw4 = taps * 2 * BN;
-    int poff[PMAX];            // element offset of the pixel inside one image of a source with pixel stride 1 (x stride later), -1 = zero
+    // Staging loads are buffer loads through per-source, per-image descriptors: a slot outside the image (the zero padding) or past
+    // the patch carries an out-of-range offset and the hardware's range check returns zeros -- no divergent branch around any load
+    // (the predicated form cost an exec-mask save / branch / restore per load and turned the counted waits into vmcnt(0): on the
+    // short K loops of NetC's stride-2 layers a quarter of a workgroup's time went into issuing them).
+    unsigned ppix[PMAX];       // index of the pixel inside its image, C2OOB = zero
     int plds[PMAX];            // LDS float offset
 #pragma unroll
     for (int i = 0; i < PMAX; ++i) {
@@ -198,19 +203,19 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
         const int py = pix / PW, px = pix - py * PW;
         const int iy = iy0 + py, ix = ix0 + px;
         const bool ok = idx < npix2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        poff[i] = ok ? (b * p.H + iy) * p.W + ix : -1;
+        ppix[i] = ok ? (unsigned)(iy * p.W + ix) : C2OOB;
         plds[i] = idx < npix2 ? pix * PIXP + q * 4 : -1;
     }
     const int q4 = (tid & 1) * 4;
-    int woff[WMAX];            // float4 index inside the chunk's slab (relative to n0), -1 = none
+    unsigned woff[WMAX];       // byte offset inside the chunk's slab, C2OOB = none
 #pragma unroll
     for (int i = 0; i < WMAX; ++i) {
         const int idx = tid + 256 * i;
         const int th = idx / BN, n = idx - th * BN;
-        woff[i] = idx < nw4 ? th * p.cout_pad + n : -1;
+        woff[i] = idx < nw4 ? (unsigned)(th * p.cout_pad + n0 + n) * 16u : C2OOB;
     }
-    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + n0;
-    const size_t wchunk = (size_t)taps * 2 * p.cout_pad;
+    const unsigned wchunk_bytes = (unsigned)taps * 2u * (unsigned)p.cout_pad * 16u;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wpk), 0, (unsigned)p.nchunk * wchunk_bytes, 0x00020000);
 
     f32x4 pr[PMAX], wr[WMAX];
     // this workgroup's K range: all chunks, or with split-K (gridDim.z > 1) an even share of the full chunks; the 4-channel
@@ -223,8 +228,13 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
     const int kend = kc1 + (has_tail ? 1 : 0);
     int seg = 0, c0 = kc0 * 8;
     while (seg + 1 < p.nseg && c0 >= p.seg[seg].cload) { c0 -= (p.seg[seg].cload + 7) / 8 * 8; ++seg; }
-    const float *sp = p.seg[seg].ptr;
     int scl = p.seg[seg].cload, sst = p.seg[seg].stride;
+    const size_t img_px = (size_t)p.H * p.W;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + (size_t)b * img_px * sst), 0,
+                                                                  (unsigned)(((img_px - 1) * sst + scl) * 4), 0x00020000);
+    unsigned pvo[PMAX];        // byte offset of the slot's 16 bytes inside the current source's image (pixel record + quad), C2OOB = zero
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) pvo[i] = ppix[i] != C2OOB ? ppix[i] * (unsigned)(sst * 4) + (unsigned)q4 * 4u : C2OOB;
 
 #ifdef PIVLFN_STAMPS
 #define CONV2_ABL(BIT) (p.dbg & (BIT))
@@ -234,15 +244,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
 #define CONV2_LOAD(CH)                                                                            \
     do {                                                                                          \
         if (CONV2_ABL(2)) break;                                                                  \
-        const int qoff_ = (scl - c0 <= 4) ? 0 : q4;      /* 4-channel tail: both quads fetch the same 16 bytes */ \
-        _Pragma("unroll") for (int i = 0; i < PMAX; ++i) {                                        \
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                       \
-            if (poff[i] >= 0) v = *reinterpret_cast<const f32x4 *>(sp + (size_t)poff[i] * sst + c0 + qoff_); \
-            pr[i] = v;                                                                            \
-        }                                                                                         \
-        const f32x4 *wc_ = wsrc + (size_t)(CH)*wchunk;                                            \
+        const unsigned back_ = (scl - c0 <= 4) ? (unsigned)q4 * 4u : 0u;      /* 4-channel tail: both quads fetch the same 16 bytes (an out-of-range offset stays out of range) */ \
+        _Pragma("unroll") for (int i = 0; i < PMAX; ++i)                                          \
+            pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(pvo[i] - back_), c0 * 4, 0)); \
         _Pragma("unroll") for (int i = 0; i < WMAX; ++i)                                          \
-            if (woff[i] >= 0) wr[i] = wc_[woff[i]];                                               \
+            wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)woff[i], (int)((unsigned)(CH)*wchunk_bytes), 0)); \
     } while (0)
 
     // K loop.  A source whose channel count is 4 (mod 8) ends in a half chunk; the packer only allows that for the LAST
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
             if (plds[i] >= 0) *reinterpret_cast<f32x4 *>(patch + plds[i]) = pr[i];
 #pragma unroll
         for (int i = 0; i < WMAX; ++i)
-            if (woff[i] >= 0) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+            if (woff[i] != C2OOB) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
         STAMP(d_commit);
         __syncthreads();
         STAMP(d_bar1);
@@ -283,7 +289,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
             if (c0 >= scl) {
                 ++seg;
                 c0 = 0;
-                sp = p.seg[seg].ptr; scl = p.seg[seg].cload; sst = p.seg[seg].stride;
+                scl = p.seg[seg].cload; sst = p.seg[seg].stride;
+                rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + (size_t)b * img_px * sst), 0,
+                                                       (unsigned)(((img_px - 1) * sst + scl) * 4), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < PMAX; ++i) pvo[i] = ppix[i] != C2OOB ? ppix[i] * (unsigned)(sst * 4) + (unsigned)q4 * 4u : C2OOB;
             }
             CONV2_LOAD(chunk + 1);
         }
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
             }
 #pragma unroll
         for (int i = 0; i < WMAX; ++i)
-            if (woff[i] >= 0) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
+            if (woff[i] != C2OOB) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
         __syncthreads();
         int tap = 0;
         for (int ky = 0; ky < p.KH; ++ky) {
@@ -613,6 +623,8 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
     p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only
     p.dbg = PIV_KNOB(7);
     const int taps = p.KH * p.KW;
+    for (int s = 0; s < p.nseg; ++s)      // 32-bit byte offsets inside one image of a source (buffer loads)
+        PIV_REQUIRE((size_t)p.H * p.W * p.seg[s].stride * 4 < 0x7fffffffull, "conv: one image of source %d (%d x %d x %d floats) exceeds the 2 GiB buffer-descriptor range", s, p.H, p.W, p.seg[s].stride);
     // Split-K when one image has too few tiles for the chip and the K loop is long enough to be worth sharing.  Decided from
     // the per-image count of canonical (4 rows x 32 px x 32 channels) tiles only -- never from the batch size or from the tile
     // shape picked below (which does depend on it): a pair's flow must not depend on its batch mates, bit for bit.

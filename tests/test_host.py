@@ -191,7 +191,7 @@ def test_no_kernel_spills_to_scratch():
     if not os.path.exists(readelf):
         pytest.skip("llvm-readelf not found")
     data = open(_lib.LIB_PATH, "rb").read()
-    allowed = {"conv_mfma2_kernelILi2ELi2ELi3ELi9E": 2}       # 168-register cap for three workgroups per CU: two lane-invariant values
+    allowed = {}              # kernel-name fragment -> spilled registers tolerated (none at present)
     seen = 0
     with tempfile.TemporaryDirectory() as tmp:
         for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
