@@ -245,12 +245,13 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 // NBW = 2 with ONE weight set: the two channel blocks are multiplied one after the other (16 MFMAs each) and a block's registers
 // receive the next chunk's fragments as soon as its MFMAs are issued -- half a step of latency cover instead of a whole one, but
 // 32 registers less than two sets, which is what lets 8 accumulators + two channel blocks fit two workgroups per CU without spills.
-#define WINO_MFMA_NW(V, NW, MB_, Z)                                                               \
+#define WINO_MFMA_NW_J(V, NW, MB_, Z, J0, J1)                                                     \
     do {                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+        _Pragma("unroll") for (int j = (J0); j < (J1); ++j)                                       \
             _Pragma("unroll") for (int jp = 0; jp < 4; ++jp)                                      \
                 acc[jp][MB_][NW] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[NW][jp][j], V[jp][j], ((Z) && j == 0) ? zero16 : acc[jp][MB_][NW], 0, 0, 0); \
     } while (0)
+#define WINO_MFMA_NW(V, NW, MB_, Z) WINO_MFMA_NW_J(V, NW, MB_, Z, 0, 4)
 #define WINO_LOADW_NW(NW, CH)                                                                     \
     do {                                                                                          \
         const float *w_ = wbase + (size_t)(CH)*wchunk + (NW)*4096 + lane * 4;                     \
@@ -271,9 +272,16 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 #define WINO_STEP2(VC, VN, CH, Z)                                                                  \
     do {                                                                                          \
         const int nx_ = (CH) + 1 < p.nchunk ? (CH) + 1 : (CH);                                    \
+        /* The first four MFMAs go out right behind the barrier and the patch loads' address work (scalar selects of the source, two \
+           compares) issues under them instead of in front of them: -1 ... -2.5 % per layer.  The fence keeps them BEHIND the barrier: \
+           left free, the compiler hoists three of them above the previous step's commit, and that build returned wrong values at \
+           full occupancy (tests/test_gpu_wino.py's full-size cases). */                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WINO_MFMA_NW_J(VC, 0, 0, Z, 0, 1);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
         WINO_LOADP(pr);                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        WINO_MFMA_NW(VC, 0, 0, Z);                                                                 \
+        WINO_MFMA_NW_J(VC, 0, 0, Z, 1, 4);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WINO_LOADW_NW(0, nx_);                                                                    \
         WSTAMP(d_blk0_);                                                                          \
@@ -343,6 +351,7 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
 #undef WINO_STEP2
 #undef WSTAMP
 #undef WINO_MFMA_NW
+#undef WINO_MFMA_NW_J
 #undef WINO_LOADW_NW
 
 #ifdef PIVLFN_STAMPS
