@@ -29,36 +29,17 @@ namespace pivlfn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-// a - b on two register pairs: v_pk_add_f32 with the second operand negated (exactly the two fp32 subtractions)
-__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
+// Differences as fused multiply-adds with -1: the compiler then emits one v_pk_fma_f32 per channel pair (a plain a - b becomes two
+// v_sub_f32: it does not fold the negation into v_pk_add_f32's modifiers).  The product is exact, so the value is the fp32
+// difference.  `m1` is -1 laundered through an empty asm so that the multiplication is not folded back into a subtraction.  (An
+// earlier version used inline-assembly v_pk_add_f32 / v_pk_fma_f32: instructions the compiler's hazard recognizer cannot see --
+// nothing waits for an in-flight MFMA result or spaces a matrix instruction behind them -- and two builds that placed them next to
+// MFMAs returned wrong values at full occupancy.  Everything here is compiler-generated again.)
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b, float m1)
 {
-    f32x2 lo, hi;
-    const f32x2 al = __builtin_shufflevector(a, a, 0, 1), ah = __builtin_shufflevector(a, a, 2, 3);
-    const f32x2 bl = __builtin_shufflevector(b, b, 0, 1), bh = __builtin_shufflevector(b, b, 2, 3);
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(al), "v"(bl));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ah), "v"(bh));
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+    return f32x4{__builtin_fmaf(m1, b[0], a[0]), __builtin_fmaf(m1, b[1], a[1]), __builtin_fmaf(m1, b[2], a[2]), __builtin_fmaf(m1, b[3], a[3])};
 }
-// max(a, b) as the bare instruction (fmaxf adds a canonicalising v_max x, x in front of every operand that came out of inline assembly)
-__device__ __forceinline__ float vmax(float a, float b)
-{
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a + s * b with s = (+-1, +-1): two v_pk_fma_f32 (the product is exact, so this is the fp32 sum or difference)
-__device__ __forceinline__ f32x4 pk_fma4(f32x2 s, f32x4 b, f32x4 a)
-{
-    f32x2 lo, hi;
-    const f32x2 al = __builtin_shufflevector(a, a, 0, 1), ah = __builtin_shufflevector(a, a, 2, 3);
-    const f32x2 bl = __builtin_shufflevector(b, b, 0, 1), bh = __builtin_shufflevector(b, b, 2, 3);
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(s), "v"(bl), "v"(al));
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(s), "v"(bh), "v"(ah));
-    return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-
 constexpr int WPW = 18;      // patch width in pixels: 8 tiles x 2 + 2
 // LDS image of one chunk's patch.  Every operand read is one 16-byte quad per lane at pixel (2 ty + r, 2 tx + c) of the lane's
 // tile (ty, tx): a stride of two pixels in both directions, which in a plain row-major image leaves only even 16-byte slots
@@ -126,7 +107,8 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sb = wave == 1 ? 1.f : -1.f;
-    const f32x2 sb2 = {sb, sb};
+    float m1 = -1.f;
+    asm("" : "+v"(m1));
     int abase[MB], bbase[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -202,17 +184,16 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
             RAW[4 + c] = smem4[(BOFF) + bbase[MB_] + ((c >> 1) + (c & 1) * 9) * WPIXQ];           \
         }                                                                                         \
     } while (0)
-// V = (B^T d B)[wave][0..3], all of it as packed fp32 instructions on channel pairs (8 v_pk_fma_f32 for the row combination with
-// the wave's sign, 8 v_pk_add_f32 for the columns, the differences through the negate modifiers): left to the compiler the
-// differences become two v_sub_f32 per pair.  Same fp32 sums and differences, same bits.
+// V = (B^T d B)[wave][0..3] as packed fp32 instructions on channel pairs: the row combination with the wave's sign and the three
+// column differences as a + m * b (v_pk_fma_f32, m = +-1: exact products), the column sum as v_pk_add_f32.
 #define WINO_XFORM(V, RAW)                                                                        \
     do {                                                                                          \
         f32x4 tt_[4];                                                                             \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) tt_[c] = pk_fma4(sb2, RAW[4 + c], RAW[c]);  \
-        V[0] = pk_sub4(tt_[0], tt_[2]);                                                           \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) tt_[c] = sub4(RAW[c], RAW[4 + c], sb);      \
+        V[0] = sub4(tt_[0], tt_[2], m1);                                                          \
         V[1] = tt_[1] + tt_[2];                                                                   \
-        V[2] = pk_sub4(tt_[2], tt_[1]);                                                           \
-        V[3] = pk_sub4(tt_[1], tt_[3]);                                                           \
+        V[2] = sub4(tt_[2], tt_[1], m1);                                                          \
+        V[3] = sub4(tt_[1], tt_[3], m1);                                                          \
     } while (0)
 #define WINO_MFMA(V, WC, MB_, Z)                                                                  \
     do {                                                                                          \
@@ -273,9 +254,8 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     do {                                                                                          \
         const int nx_ = (CH) + 1 < p.nchunk ? (CH) + 1 : (CH);                                    \
         /* The first four MFMAs go out right behind the barrier and the patch loads' address work (scalar selects of the source, two \
-           compares) issues under them instead of in front of them: -1 ... -2.5 % per layer.  The fence keeps them BEHIND the barrier: \
-           left free, the compiler hoists three of them above the previous step's commit, and that build returned wrong values at \
-           full occupancy (tests/test_gpu_wino.py's full-size cases). */                          \
+           compares) issues under them instead of in front of them: -1 ... -2.5 % per layer.  The fence pins them behind the barrier \
+           (left free the compiler hoists three of them above the previous step's commit: no faster). */ \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WINO_MFMA_NW_J(VC, 0, 0, Z, 0, 1);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                        \
@@ -372,7 +352,7 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
                 for (int jp = 0; jp < 4; ++jp)
                     m[jp] = f32x4{acc[jp][mb][nw][4 * rg + 0], acc[jp][mb][nw][4 * rg + 1], acc[jp][mb][nw][4 * rg + 2], acc[jp][mb][nw][4 * rg + 3]};
                 xch[((((mb * NBW + nw) * 4 + wave) * 2 + 0) * 4 + rg) * 64 + lane] = (m[0] + m[1]) + m[2];
-                xch[((((mb * NBW + nw) * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = pk_sub4(pk_sub4(m[1], m[2]), m[3]);
+                xch[((((mb * NBW + nw) * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = sub4(sub4(m[1], m[2], m1), m[3], m1);
             }
     __syncthreads();
     const int pp = wave >> 1, qq = wave & 1;      // this wave finishes output pixel (pp, qq) of every tile
@@ -392,11 +372,10 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
                 const f32x4 *x = xch + (((mb * NBW + nw) * 4 * 2 + qq) * 4 + rg) * 64 + lane;     // wave i at x[i * 2 * 4 * 64]
                 f32x4 y;
                 if (pp == 0) y = (x[0] + x[1 * 512]) + x[2 * 512];
-                else y = pk_sub4(pk_sub4(x[1 * 512], x[2 * 512]), x[3 * 512]);
+                else y = sub4(sub4(x[1 * 512], x[2 * 512], m1), x[3 * 512], m1);
                 y += bias4[rg];
-                if (p.lrelu) {      // v >= 0 ? v : 0.1 v  ==  max(v, 0.1 v), two instructions per pair of values less than compare + select
-                    const f32x4 t = 0.1f * y;
-                    y[0] = vmax(y[0], t[0]); y[1] = vmax(y[1], t[1]); y[2] = vmax(y[2], t[2]); y[3] = vmax(y[3], t[3]);
+                if (p.lrelu) {
+                    y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
                 }
                 if (ok && cb + 8 * rg < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * rg) = y;
             }
