@@ -266,13 +266,18 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
         WINO_LOADW_NW(0, nx_);                                                                    \
         WSTAMP(d_blk0_);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        WINO_MFMA_NW(VC, 1, 0, Z);                                                                 \
+        WINO_MFMA_NW_J(VC, 1, 0, Z, 0, 3);                                                        \
         WINO_READ(raw, bo1, 0);                                                                   \
         WINO_XFORM(VN, raw);                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                        \
+        /* the commit (wait for the patch loads, two LDS writes) goes in front of the block's last four MFMAs, so that the matrix \
+           pipe still has ~256 cycles of this wave's work queued while the wave walks into the barrier: -1 ... -1.7 % per layer */ \
+        WINO_COMMIT(pr, bo2);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WINO_MFMA_NW_J(VC, 1, 0, Z, 3, 4);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
         WSTAMP(d_blk1_);                                                                          \
         WINO_LOADW_NW(1, nx_);                                                                    \
-        WINO_COMMIT(pr, bo2);                                                                     \
         WSTAMP(d_commit_);                                                                        \
         __syncthreads();                                                                          \
         WSTAMP(d_bar_);                                                                           \
