@@ -36,9 +36,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // earlier version used inline-assembly v_pk_add_f32 / v_pk_fma_f32: instructions the compiler's hazard recognizer cannot see --
 // nothing waits for an in-flight MFMA result or spaces a matrix instruction behind them -- and two builds that placed them next to
 // MFMAs returned wrong values at full occupancy.  Everything here is compiler-generated again.)
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b, float m1)
 {
-    return f32x4{__builtin_fmaf(m1, b[0], a[0]), __builtin_fmaf(m1, b[1], a[1]), __builtin_fmaf(m1, b[2], a[2]), __builtin_fmaf(m1, b[3], a[3])};
+    // two <2 x float> fused multiply-adds: the form the compiler keeps as v_pk_fma_f32 (four scalar fmaf calls are only partly re-packed)
+    const f32x2 m = {m1, m1};
+    const f32x2 lo = __builtin_elementwise_fma(m, __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(a, a, 0, 1));
+    const f32x2 hi = __builtin_elementwise_fma(m, __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(a, a, 2, 3));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 constexpr int WPW = 18;      // patch width in pixels: 8 tiles x 2 + 2
 // LDS image of one chunk's patch.  Every operand read is one 16-byte quad per lane at pixel (2 ty + r, 2 tx + c) of the lane's
