@@ -94,6 +94,19 @@ def test_forward_vs_oracle_fresh_seed(nets, dev):
         _check(got, want, f"{model} 2x128x96")
 
 
+def test_forward_vs_oracle_mid_size(nets, dev):
+    """512 x 448, one pair, oracle run here on the CPU (~2 s): the size from which levels 1 and 2 launch every tile shape of the
+    Winograd kernel at full occupancy (two workgroups per CU, several generations) and the 7 x 1 / 7 x 7 layers run on their
+    streaming matrix-core kernels -- the small fixtures never get there.  Same tolerance as every end-to-end case."""
+    a, b = synth.particle_batch(1, 512, 448, seed=4242)
+    i1, i2 = torch.from_numpy(a), torch.from_numpy(b)
+    onet = orc.make_net("piv", synth.generate_weights("piv", 0), corr="c")
+    with torch.no_grad():
+        want = onet.forward(i1, i2).numpy()
+    got = nets["piv"](i1.to(dev), i2.to(dev)).cpu().numpy()
+    _check(got, want, "piv 1x512x448")
+
+
 def test_batch_consistency_and_argument_errors(nets, dev):
     a, b = synth.particle_batch(3, 64, 96, seed=31)
     i1, i2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
