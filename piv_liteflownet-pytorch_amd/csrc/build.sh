@@ -22,7 +22,9 @@ build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags
   for f in $SRCS; do
     objs+=("$OBJ/$f.o")
     if [ ! -f "$OBJ/$f.o" ] || [ "$f.hip" -nt "$OBJ/$f.o" ]; then
-      hipcc $FLAGS -c "$f.hip" -o "$OBJ/$f.o" &
+      # warp_corr: the SLP vectoriser packs the consumers' fma chains into v_pk_fma_f32 behind 2-4 v_mov each (measured in the ISA)
+      local PERFILE=""; [ "$f" = "warp_corr" ] && PERFILE="-fno-slp-vectorize"
+      hipcc $FLAGS $PERFILE -c "$f.hip" -o "$OBJ/$f.o" &
       pids+=($!)
     fi
   done

@@ -21,11 +21,13 @@
 #include <cstdlib>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace pivlfn {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int TO = 8;
 constexpr int TP = TO + 6;
@@ -44,6 +46,7 @@ struct WcParams {
     int B, C, H, W, s, Ho, Wo, leaky;
     int dbg;      // ablation mask for tools/bench_ops.py (0 in production): 1 skip dot products, 2 skip gathers, 4 skip store, 8 exit at entry
     int strips;   // 1: walk the tiles in strips of 8 tile rows, column by column (wide images; see warp_corr_v3_kernel)
+    int rl;       // v6: run length (vertically consecutive tiles per run), set by its launcher
     unsigned long long *stamps;   // tools build only: per-workgroup phase stamps (16 u64 per record, 2 records per workgroup); nullptr in production
 };
 
@@ -816,6 +819,536 @@ static int launch_wc(const WcParams &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
+
+// ---- v6: one persistent workgroup per CU, specialised waves, sliding window over vertical runs of tiles (round 4) -----------
+// Why: phase ablations of v3 showed that gathers, dot products, output store and the per-tile skeleton of two
+// co-resident workgroups add up almost serially (18.6 + 11.4 + 11 + 10 us against 43 measured) although no unit of the CU is
+// more than 40 % busy.  v6 gives them to different waves of ONE 1024-thread workgroup that walks the tiles of its XCD band:
+//   waves 8..15  producers: per 32-channel chunk three (position, 16-byte quad) items each = 12 buffer loads in flight per lane
+//                (100 KB per CU), rolling: wait for the oldest item, blend, store to LDS, issue the same item of the NEXT chunk
+//                (or of the next tile: its taps are computed from a flow value fetched one phase ahead) -- the CU's load path
+//                never drains, across chunk and tile boundaries alike; they also store the previous tile's output rows.
+//   wave  7      helper: the f1 tile (8 loads per lane) and the 4 left-over positions 192..195.
+//   waves 0..6   consumers: wave = displacement column dx; lane = (row half h, column j, channel quad g); a lane owns the 4
+//                output rows of its half at column j and one 16-byte quad of a 16-channel plane.  One ds_read_b128 of the warped
+//                tile at row r feeds the displacements dy = r - yy of all four rows: 14 reads per 112 fused multiply-adds
+//                (v3: 20, v4: 40).  28 accumulators per lane, summed over the four quad lanes once per tile (DPP).
+// One barrier per chunk; chunk m lives in LDS buffer m & 1; while the consumers read chunk m the producers fill chunk m + 1 and
+// have chunk m + 2 in flight.  A step cannot be shorter than one memory round trip, so what a launch costs is (bytes gathered) /
+// (bytes in flight per CU / latency): the second lever is to gather fewer bytes.  SLIDING WINDOW (C = 64, two chunks, so that
+// chunk k of every tile lives in buffer k): a workgroup takes RUNS of vertically consecutive tiles; a tile's 14 rows of warped
+// positions live in a ring of 32 rows per plane, the tile below re-uses its last 6 rows and only 8 new rows (112 of 196 positions)
+// are gathered -- 0.57-0.63 x the loads, blends and LDS stores per tile.  Runs of neighbouring tile columns run on the same XCD
+// at the same time (the horizontal halo is shared through its L2).
+// Summation order (the one order of this file's channels-last kernels since round 4; every launch of a level uses v6, so a
+// pair's bits do not depend on its batch): a value is the sum of four chains S_g, g = (c / 4) % 4, each over c = 16 k + 4 g + e
+// ascending with fmaf, combined as (S_0 + S_1) + (S_2 + S_3); the four bilinear taps are blended by blend_taps (tap order).
+// LDS: a chunk buffer = two 16-channel planes of warped positions [32 ring rows][14][16] + two of the f1 tile [64 pixels][16];
+// each plane is padded by 64 bytes so that the two planes an 8-lane store group writes fall on different bank halves; every
+// ds_read_b128 group of the consumers covers four positions whose 64-byte vectors are 64 banks apart: conflict-free.
+constexpr int K6_RING = 32;                                // position rows per plane (power of two; >= 14 + 8)
+constexpr int K6_ROW = TP * 64;                            // bytes of one position row in a 16-channel plane
+constexpr int K6_PLANE = K6_RING * K6_ROW + 64;
+constexpr int K6_F1PLANE = 64 * 64 + 64;
+constexpr int K6_F1OFF = 2 * K6_PLANE;
+constexpr int K6_BUFDUMP = 2 * K6_PLANE + 2 * K6_F1PLANE;  // where items without a position store (1 KB at the end of each buffer)
+constexpr int K6_BUF = K6_BUFDUMP + 1024;                  // 66816
+constexpr int K6_TR = 2 * K6_BUF;                          // output tile [64 pixels][56] floats
+constexpr int K6_TAPS = K6_TR + 64 * OUTC * 4;             // tap tables of two tiles: [2][196 positions]{4 byte offsets, 4 weights}
+constexpr int K6_TAPTBL = NPOS * 32;
+constexpr int K6_LDS = K6_TAPS + 2 * K6_TAPTBL;            // 160512 (of 163840)
+
+struct K6Sched { int tiles_x, tiles_y, rl, rpc, r0, rstep, nruns, slide; };
+// Work unit of a workgroup: a tile, or (sliding kernel) the PRIMING unit in front of a run's first tile, which gathers position
+// rows 0..5 of that tile (84 positions) while every tile unit gathers rows 6..13 (112 positions) -- so that all phases of the
+// sliding kernel move at most 128 positions (two items per lane) and are one code shape.
+struct K6Iter { int ri, i, len, rb, n, prime; };           // run (index in this workgroup's list), tile in run, run length, ring base row, units before this one
+struct K6Tile { int b, oy0, ox0, prime, rb, par; };        // par: which tap table
+
+__device__ __forceinline__ void k6_run(const K6Sched &S, int ri, int &b, int &rr, int &tx)
+{
+    const int id = S.r0 + ri * S.rstep;
+    tx = id % S.tiles_x;
+    const int t = id / S.tiles_x;
+    rr = t % S.rpc;
+    b = t / S.rpc;
+}
+__device__ __forceinline__ K6Iter k6_begin(const K6Sched &S)
+{
+    K6Iter it{0, 0, 1, 0, 0, S.slide};
+    if (S.nruns > 0) { int b, rr, tx; k6_run(S, 0, b, rr, tx); it.len = min(S.rl, S.tiles_y - rr * S.rl); }
+    return it;
+}
+__device__ __forceinline__ K6Tile k6_tile(const K6Sched &S, const K6Iter &it)
+{
+    int b, rr, tx;
+    k6_run(S, it.ri, b, rr, tx);
+    return K6Tile{b, (rr * S.rl + it.i) * TO, tx * TO, it.prime, it.rb, it.n & 1};
+}
+__device__ __forceinline__ K6Iter k6_next(const K6Sched &S, K6Iter it)      // the caller checks ri < nruns before using the result
+{
+    ++it.n;
+    if (it.prime) { it.prime = 0; return it; }
+    if (it.i + 1 < it.len) { ++it.i; it.rb = (it.rb + 8) & (K6_RING - 1); return it; }
+    ++it.ri; it.i = 0; it.rb = 0; it.prime = S.slide;
+    if (it.ri < S.nruns) { int b, rr, tx; k6_run(S, it.ri, b, rr, tx); it.len = min(S.rl, S.tiles_y - rr * S.rl); }
+    return it;
+}
+
+__device__ __forceinline__ f32x4 bload_s(__amdgpu_buffer_rsrc_t rs, unsigned off, int soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, soff, 0));
+}
+
+__device__ __forceinline__ float dpp_xor1(float v)      // lane ^ 1 inside each quad (quad_perm [1,0,3,2])
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v)      // lane ^ 2 inside each quad (quad_perm [2,3,0,1])
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
+// Taps of one warped position: byte offsets of the four neighbours' pixels (OOB = contributes zero) and bilinear weights.
+template <bool HASFLOW>
+__device__ __forceinline__ void k6_taps(const WcParams &p, unsigned pix_bytes, int iy, int ix, float2 uv, i32x4 &o, f32x4 &w)
+{
+    const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    if constexpr (HASFLOW) {
+        const Taps t = make_taps((float)ix + uv.x * p.scale, (float)iy + uv.y * p.scale, p.H, p.W);
+        o[0] = (int)((!in || t.o00 < 0) ? OOB : (unsigned)t.o00 * pix_bytes);
+        o[1] = (int)((!in || t.o01 < 0) ? OOB : (unsigned)t.o01 * pix_bytes);
+        o[2] = (int)((!in || t.o10 < 0) ? OOB : (unsigned)t.o10 * pix_bytes);
+        o[3] = (int)((!in || t.o11 < 0) ? OOB : (unsigned)t.o11 * pix_bytes);
+        w = f32x4{t.w00, t.w01, t.w10, t.w11};
+    } else {
+        o[0] = (int)(in ? (unsigned)(iy * p.W + ix) * pix_bytes : OOB);
+        o[1] = o[2] = o[3] = (int)OOB;
+        w = f32x4{1.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__device__ __forceinline__ float2 k6_flow(const WcParams &p, __amdgpu_buffer_rsrc_t rsf, int b, int iy, int ix)
+{
+    const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const unsigned off = in ? (unsigned)((b * p.H + iy) * p.W + ix) * 16u : OOB;
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsf, (int)off, 0, 0));
+}
+
+template <int NT>
+__device__ __forceinline__ f32x4 k6_blend(const f32x4 w, const f32x4 (&x)[NT])
+{
+    if constexpr (NT == 4) return blend_taps(w[0], w[1], w[2], w[3], x[0], x[1], x[2], x[3]);
+    else return w[0] * x[0];
+}
+
+// Tools build: lane 0 of one wave per role (0 consumer wave 0, 1 helper, 2 producer wave 8, 3 producer wave 15) stamps s_memtime
+// at three points of every step (after the barrier, after its first wait, at the end of its work): 96 stamps per role and workgroup.
+#ifdef PIVLFN_STAMPS
+#define K6_STAMP(role, idx)                                                                        \
+    do {                                                                                           \
+        if (p.stamps && lane == 0 && (unsigned)(idx) < 96u) p.stamps[((size_t)blockIdx.x * 4 + (role)) * 96 + (idx)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define K6_STAMP(role, idx) do { } while (0)
+#endif
+
+// NS = items per producer lane and chunk: 4 (every tile gathers all 196 positions; any C >= 64) or 2 (sliding window over runs of
+// tiles; C = 64).  Same arithmetic, same bits.
+template <bool HASFLOW, int NS>
+__global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+    constexpr int NT = HASFLOW ? 4 : 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // Run schedule of this workgroup.  Runs (rl vertically consecutive tiles of one tile column) are numbered with the tile
+    // column fastest; workgroup (xcd = id & 7, w = id >> 3) walks runs w, w + nw, ... of the XCD's contiguous band of run ids, so the
+    // workgroups running together on an XCD work on neighbouring tile columns (halos shared in its L2).  With a workgroup per run
+    // the ids are remapped the same way.
+    K6Sched S;
+    S.tiles_x = (p.Wo + TO - 1) / TO; S.tiles_y = (p.Ho + TO - 1) / TO; S.rl = p.rl; S.slide = NS == 2;
+    S.rpc = (S.tiles_y + S.rl - 1) / S.rl;
+    const int nruns_all = S.tiles_x * S.rpc * p.B;
+    if ((int)gridDim.x == nruns_all) {
+        S.nruns = 1; S.r0 = xcd_remap(blockIdx.x, nruns_all); S.rstep = 0;
+    } else {
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, nw = gridDim.x >> 3;
+        const int q = nruns_all >> 3, r = nruns_all & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int cnt = q + (xcd < r ? 1 : 0);
+        S.nruns = w < cnt ? (cnt - w + nw - 1) / nw : 0;
+        S.r0 = base + w; S.rstep = nw;
+    }
+    if (S.nruns == 0 || (p.dbg & 8)) return;
+    const int nch = p.C >> 5;                      // 32-channel chunks per tile (>= 2, checked by the launcher)
+    const size_t img = (size_t)p.H * p.W;
+    const unsigned img_bytes = (unsigned)(img * p.C * sizeof(float));
+    const unsigned pix_bytes = (unsigned)p.C * 4u;
+
+    if (wave < 7) {
+        // ---------------------------------------------------------------- consumers: dot products
+        const int dx = wave;
+        const int g = lane & 3, j = (lane >> 2) & 7, h = lane >> 5;
+        const unsigned a0 = (unsigned)((j + dx) * 64 + g * 16);
+        const unsigned f0 = (unsigned)(K6_F1OFF + (4 * h * 8 + j) * 64 + g * 16);
+        const float cf = (float)p.C, cinv = pow2_reciprocal(p.C);
+        // Accumulators as pairs for v_pk_fma_f32: one read of the warped tile at row r feeds output rows yy and yy + 1 of a row pair
+        // (displacements dy = r - yy and r - yy - 1), with the f1 values of the two rows side by side in a register pair (the
+        // helper stores the f1 tile interleaved that way) and the warped value broadcast: P0[i] = {acc[0][i + 1], acc[1][i]},
+        // P1[i] = {acc[2][i + 1], acc[3][i]}; the four displacements without a partner (acc[0][0], acc[1][6], acc[2][0], acc[3][6])
+        // stay scalar.  Every accumulator is still one fmaf chain over its channels in ascending order: same bits, 64 instructions
+        // per 16-channel plane instead of 112.
+        f32x2 P0[6], P1[6];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { P0[i] = f32x2{0.f, 0.f}; P1[i] = f32x2{0.f, 0.f}; }
+        const unsigned fp0 = (unsigned)(K6_F1OFF + (4 * h) * 512 + (j * 4 + g) * 16);      // row pair 2h: + half * 512; row pair 2h + 1: + 1024
+        int m = 0;
+#pragma unroll 1
+        for (K6Iter it = k6_begin(S); it.ri < S.nruns; it = k6_next(S, it)) {
+            unsigned rowoff[10];          // ring rows of this lane's 10 position rows
+#pragma unroll
+            for (int r = 0; r < 10; ++r) rowoff[r] = (unsigned)((it.rb + 4 * h + r) & (K6_RING - 1)) * K6_ROW + a0;
+            const bool work = !it.prime;      // a priming unit only fills rows of the ring
+#pragma unroll 1
+            for (int k = 0; k < nch; ++k, ++m) {
+                if (wave == 0) K6_STAMP(0, 3 * m - 1);
+                __syncthreads();
+                if (wave == 0) K6_STAMP(0, 3 * m);
+                const unsigned bo = (m & 1) ? (unsigned)K6_BUF : 0u;
+                if (work && !(p.dbg & 1)) {
+                    const char *f1b = lds + fp0 + bo;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        f32x2 FA[4], FB[4];       // {f1 row 0, row 1}[e], {row 2, row 3}[e] of this lane's half, e = 0..3
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const f32x4 qa = *reinterpret_cast<const f32x4 *>(f1b + sub * K6_F1PLANE + hf * 512);
+                            const f32x4 qb = *reinterpret_cast<const f32x4 *>(f1b + sub * K6_F1PLANE + 1024 + hf * 512);
+                            FA[2 * hf] = f32x2{qa[0], qa[1]}; FA[2 * hf + 1] = f32x2{qa[2], qa[3]};
+                            FB[2 * hf] = f32x2{qb[0], qb[1]}; FB[2 * hf + 1] = f32x2{qb[2], qb[3]};
+                        }
+                        f32x4 vq[2];              // row r + 1 is read before row r is used
+                        vq[0] = *reinterpret_cast<const f32x4 *>(lds + (rowoff[0] + bo) + sub * K6_PLANE);
+#pragma unroll
+                        for (int r = 0; r < 10; ++r) {
+                            if (r < 9) vq[(r + 1) & 1] = *reinterpret_cast<const f32x4 *>(lds + (rowoff[r + 1] + bo) + sub * K6_PLANE);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const f32x4 v = vq[r & 1];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const f32x2 vv = f32x2{v[e], v[e]};
+                                if (r == 0) s0 = fmaf(FA[e][0], v[e], s0);
+                                if (r >= 1 && r <= 6) P0[r - 1] = __builtin_elementwise_fma(FA[e], vv, P0[r - 1]);
+                                if (r == 7) s1 = fmaf(FA[e][1], v[e], s1);
+                                if (r == 2) s2 = fmaf(FB[e][0], v[e], s2);
+                                if (r >= 3 && r <= 8) P1[r - 3] = __builtin_elementwise_fma(FB[e], vv, P1[r - 3]);
+                                if (r == 9) s3 = fmaf(FB[e][1], v[e], s3);
+                            }
+                        }
+                    }
+                }
+                if (wave == 0) K6_STAMP(0, 3 * m + 1);
+            }
+            float acc[28];                // acc[yy * 7 + dy]
+#pragma unroll
+            for (int dy = 0; dy < 7; ++dy) {
+                acc[dy] = dy == 0 ? s0 : P0[dy > 0 ? dy - 1 : 0][0];
+                acc[7 + dy] = dy == 6 ? s1 : P0[dy < 6 ? dy : 0][1];
+                acc[14 + dy] = dy == 0 ? s2 : P1[dy > 0 ? dy - 1 : 0][0];
+                acc[21 + dy] = dy == 6 ? s3 : P1[dy < 6 ? dy : 0][1];
+            }
+            if (!work) continue;
+            // tile done: (S_0 + S_1) + (S_2 + S_3) over the four quad lanes as a reduce-scatter -- after the two steps lane g holds
+            // the 7 displacement rows dy of output row yy = 2 (g & 1) + (g >> 1) of its half
+            const bool b0 = lane & 1, b1 = lane & 2;
+            float r1[14], r2[7];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                const float mine = b0 ? acc[14 + i] : acc[i], send = b0 ? acc[i] : acc[14 + i];
+                r1[i] = mine + dpp_xor1(send);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const float mine = b1 ? r1[7 + i] : r1[i], send = b1 ? r1[i] : r1[7 + i];
+                r2[i] = mine + dpp_xor2(send);
+            }
+            const int yy = 2 * (lane & 1) + ((lane >> 1) & 1);
+            float *tr = reinterpret_cast<float *>(lds + K6_TR) + ((4 * h + yy) * 8 + j) * OUTC + dx;
+#pragma unroll
+            for (int dy = 0; dy < 7; ++dy) {
+                float v = mean_over_c(r2[dy], cf, cinv);
+                if (p.leaky) v = lrelu01(v);
+                tr[7 * dy] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { P0[i] = f32x2{0.f, 0.f}; P1[i] = f32x2{0.f, 0.f}; }
+            s0 = s1 = s2 = s3 = 0.f;
+        }
+        __syncthreads();
+        return;
+    }
+
+    // descriptors: flow of the whole batch (offsets carry the image), features per image
+    const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.flow ? p.flow : p.f1), 0,
+                                                                         p.flow ? (unsigned)((size_t)p.B * img * 16) : 0u, 0x00020000);
+    K6Iter cur = k6_begin(S);
+    K6Tile T = k6_tile(S, cur);
+
+    if (wave == 7) {
+        // ---------------------------------------------------------------- helper: the f1 tile
+        const int fq8 = lane & 7, fcol = lane >> 3;                 // f1 item e: pixel (row e, column fcol), quad fq8
+        const unsigned f1dst = (unsigned)(K6_F1OFF + (fq8 >> 2) * K6_F1PLANE + (fcol * 4 + (fq8 & 3)) * 16);    // + (row pair * 2 + half) * 512: [4][2][8 columns][4 quads] x 16 bytes
+        {   // exact zeros in the 7 padding lanes of the output tile, once
+            float *tr = reinterpret_cast<float *>(lds + K6_TR) + lane * OUTC;
+#pragma unroll
+            for (int d = 49; d < OUTC; ++d) tr[d] = 0.f;
+        }
+        f32x4 fx[8];
+        unsigned f1o;
+        auto set_tile = [&](const K6Tile &t) {
+            const int ox = t.ox0 + fcol;
+            f1o = ox < p.Wo ? (unsigned)((t.oy0 * p.s) * p.W + ox * p.s) * pix_bytes + 16u * fq8 : OOB;
+        };
+        auto issue = [&](const K6Tile &t, __amdgpu_buffer_rsrc_t r1, int soff, bool valid) {
+            const unsigned rowb = (unsigned)(p.s * p.W) * pix_bytes;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fx[e] = bload_s(r1, (valid && f1o != OOB && t.oy0 + e < p.Ho) ? f1o + e * rowb : OOB, soff);
+        };
+        __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)T.b * img * p.C), 0, img_bytes, 0x00020000);
+        set_tile(T);
+        issue(T, rs1, 0, true);
+        int m = 0;
+#pragma unroll 1
+        while (cur.ri < S.nruns) {
+            const K6Iter nxt = k6_next(S, cur);
+            const bool has_next = nxt.ri < S.nruns;
+            const K6Tile Tn = has_next ? k6_tile(S, nxt) : T;
+            const __amdgpu_buffer_rsrc_t rs1n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)Tn.b * img * p.C), 0, img_bytes, 0x00020000);
+#pragma unroll 1
+            for (int k = 0; k < nch; ++k, ++m) {
+                K6_STAMP(1, 3 * m - 1);
+                if (m > 0) __syncthreads();
+                K6_STAMP(1, 3 * m);
+                const bool last = k == nch - 1;
+                char *buf = lds + ((m & 1) ? K6_BUF : 0);
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) {        // rows 2 rp, 2 rp + 1 side by side (the consumers' register pairs)
+                    const f32x4 ra = fx[2 * rp], rb = fx[2 * rp + 1];
+                    *reinterpret_cast<f32x4 *>(buf + f1dst + (2 * rp) * 512) = f32x4{ra[0], rb[0], ra[1], rb[1]};
+                    *reinterpret_cast<f32x4 *>(buf + f1dst + (2 * rp + 1) * 512) = f32x4{ra[2], rb[2], ra[3], rb[3]};
+                }
+                K6_STAMP(1, 3 * m + 1);
+                if (last) {
+                    set_tile(Tn);
+                    issue(Tn, rs1n, 0, has_next);
+                } else {
+                    issue(T, rs1, (k + 1) * 128, true);
+                }
+            }
+            T = Tn; rs1 = rs1n; cur = nxt;
+        }
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+
+    // -------------------------------------------------------------------- producers: taps, gather, blend, LDS; output rows
+    // Per 32-channel chunk a lane owns up to four (position, 16-byte quad) items = 16 buffer loads in flight: item u is position
+    // base + 64 u + (lane id >> 3), quad (lane id & 7); a fresh tile has 196 positions (4 items, the last one 4 positions wide), a
+    // tile below its predecessor 112 (2 items).  Taps: the 32 positions a WAVE gathers are computed once, by its lanes 0..31, from
+    // a flow value fetched at the start of the tile's first phase, and go through a table in LDS (32 bytes per position; only this
+    // wave reads its entries); per item and phase a lane reads its weights and offsets from there.  (First version: every lane
+    // computed the taps of its three items itself -- ~4000 cycles of index arithmetic per tile on the critical path, phase stamps.)
+    const int tp = tid - 512, wp = wave - 8;
+    f32x4 x[NS][NT];
+    unsigned dst[NS], tof[NS];                       // per item: LDS destination (buffer-relative) and tap-table entry of this unit
+    float2 fl = {0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)p.B * p.Ho * p.Wo * OUTC * 4), 0x00020000);
+    auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    // Output rows of tile t from the LDS image: 896 quads over 512 lanes, as buffer stores whose offset is out of range for lanes
+    // (or phases: `on`) with nothing to store -- no branch, so the counted waits of the phase stay counted.
+    auto store_tile = [&](int tpl, const K6Tile &t, bool on) {
+        const float *tr = reinterpret_cast<const float *>(lds + K6_TR);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int item = min(tpl + 512 * u, 64 * (OUTC / 4) - 1);
+            const int px = item / (OUTC / 4), q = item - px * (OUTC / 4);
+            const int oy = t.oy0 + (px >> 3), ox = t.ox0 + (px & 7);
+            const bool ok = on & (tpl + 512 * u < 64 * (OUTC / 4)) & (oy < p.Ho) & (ox < p.Wo) & !(p.dbg & 4);      // & not &&: no short-circuit branches
+            const unsigned off = ok ? (unsigned)(((t.b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) * 4u : OOB;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + px * OUTC + 4 * q);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rso, (int)off, 0, 0);
+        }
+    };
+    // positions of unit t: [base, lim) -- all 196 (NS = 4), or rows 0..5 (priming) / rows 6..13 (tile) of the sliding kernel
+    auto pos_base = [&](const K6Tile &t) { return NS == 4 ? 0 : (t.prime ? 0 : 6 * TP); };
+    auto pos_lim = [&](const K6Tile &t) { return NS == 4 ? NPOS : (t.prime ? 6 * TP : NPOS); };
+    auto slot_params = [&](int tpl, const K6Tile &t, unsigned (&d)[NS], unsigned (&tf)[NS]) {
+        const int q8 = tpl & 7;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int pos = pos_base(t) + 64 * u + (tpl >> 3), pp = min(pos, NPOS - 1);
+            const int r = pp / TP, c = pp - r * TP;
+            d[u] = pos < pos_lim(t) ? (unsigned)((q8 >> 2) * K6_PLANE + (q8 & 3) * 16 + ((t.rb + r) & (K6_RING - 1)) * K6_ROW + c * 64)
+                                    : (unsigned)(K6_BUFDUMP + (tpl & 63) * 16);
+            tf[u] = (unsigned)(K6_TAPS + t.par * K6_TAPTBL + pp * 32);
+        }
+    };
+    // the position whose taps this lane computes for unit t (8 NS lanes of the wave; the others repeat them), or >= lim
+    auto tap_pos = [&](const K6Tile &t) { return pos_base(t) + 64 * ((lane & (8 * NS - 1)) >> 3) + 8 * wp + (lane & 7); };
+    auto tap_flow = [&](const K6Tile &t) {
+        const int pos = min(tap_pos(t), NPOS - 1);
+        return k6_flow(p, rsf, t.b, (t.oy0 + pos / TP - 3) * p.s, (t.ox0 + pos % TP - 3) * p.s);
+    };
+    auto tap_write = [&](const K6Tile &t, float2 uv) {
+        const int pos = tap_pos(t), pp = min(pos, NPOS - 1);
+        i32x4 o; f32x4 w;
+        k6_taps<HASFLOW>(p, pix_bytes, (t.oy0 + pp / TP - 3) * p.s, (t.ox0 + pp % TP - 3) * p.s, uv, o, w);
+        if (pos < pos_lim(t)) {
+            char *e = lds + K6_TAPS + t.par * K6_TAPTBL + pp * 32;
+            *reinterpret_cast<i32x4 *>(e) = o;
+            *reinterpret_cast<f32x4 *>(e + 16) = w;
+        }
+    };
+    auto issue_item = [&](int tpl, int u, const i32x4 o, unsigned d, __amdgpu_buffer_rsrc_t rs, int soff, bool valid) {
+        const bool ok = valid & (d < (unsigned)K6_BUFDUMP);
+        const unsigned qoff = 16u * (tpl & 7);
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) x[u][kk] = bload_s(rs, ok ? (unsigned)o[kk] + qoff : OOB, soff);
+    };
+    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)T.b * img * p.C), 0, img_bytes, 0x00020000);
+    // prologue: this wave's taps of the first tile, then its chunk 0 in flight
+    if (HASFLOW) fl = tap_flow(T);
+    tap_write(T, fl);
+    slot_params(tp, T, dst, tof);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the table entries this wave wrote are read back below
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        issue_item(tp, u, *reinterpret_cast<const i32x4 *>(lds + tof[u]), dst[u], rs2, 0, !(p.dbg & 2));
+        __builtin_amdgcn_sched_barrier(0);         // item order = the phases' order: the wait counts at the loop head merge both paths
+    }
+    // A tile's chunks are walked as code instances (first / middle / last chunk  x  items of this tile  x  items of the next tile):
+    // straight-line, with a sched_barrier between items, so that every wait is a counted vmcnt in rolling order -- wait for the
+    // oldest item, blend, store to LDS, issue the same item of the next chunk (in the last chunk: of the next tile).  The table
+    // entries of item u + 1 are read before item u is processed.  The first chunk's phase ends with the next tile's taps.
+    int m = 0;
+    K6Tile Tprev = T, Tn = T;
+    __amdgpu_buffer_rsrc_t rs2n = rs2;
+    bool has_next = false;
+    auto phase = [&](auto first_c, auto last_c, int k, bool store_prev) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        if (wave == 8) K6_STAMP(2, 3 * m - 1); else if (wave == 15) K6_STAMP(3, 3 * m - 1);
+        if (m > 0) __syncthreads();
+        if (wave == 8) K6_STAMP(2, 3 * m); else if (wave == 15) K6_STAMP(3, 3 * m);
+        const int tpl = launder(tp);
+        store_tile(tpl, Tprev, store_prev);         // the previous tile's last chunk was step m - 2
+        if constexpr (FIRST && HASFLOW) fl = tap_flow(Tn);
+        const unsigned bufbase = (m & 1) ? (unsigned)K6_BUF : 0u;
+        const int soff = LAST ? 0 : (k + 1) * 128;
+        const bool valid = (!LAST || has_next) && !(p.dbg & 2);      // dbg & 2 (tools): every gather out of range -- issued, no data moved
+        unsigned dstn[NS], tofn[NS];                // the next unit's item parameters (last phase: its loads go out here)
+        if constexpr (LAST) slot_params(tpl, Tn, dstn, tofn);
+        const unsigned (&tfi)[NS] = LAST ? tofn : tof;
+        const unsigned (&di)[NS] = LAST ? dstn : dst;
+        f32x4 w = *reinterpret_cast<const f32x4 *>(lds + tof[0] + 16);
+        i32x4 o = *reinterpret_cast<const i32x4 *>(lds + tfi[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            f32x4 wn = w; i32x4 on = o;
+            if (u + 1 < NS) {
+                wn = *reinterpret_cast<const f32x4 *>(lds + tof[u + 1] + 16);
+                on = *reinterpret_cast<const i32x4 *>(lds + tfi[u + 1]);
+            }
+            *reinterpret_cast<f32x4 *>(lds + bufbase + dst[u]) = k6_blend<NT>(w, x[u]);
+            if (u == 0) { if (wave == 8) K6_STAMP(2, 3 * m + 1); else if (wave == 15) K6_STAMP(3, 3 * m + 1); }
+            issue_item(tpl, u, o, di[u], LAST ? rs2n : rs2, soff, valid);
+            w = wn; o = on;
+            __builtin_amdgcn_sched_barrier(0);      // rolling order: left alone, the scheduler consumes all items first and issues the loads as one burst (the queue drains every phase)
+        }
+        if constexpr (FIRST) tap_write(Tn, fl);     // the next unit's taps (its flow went out at the top of this phase)
+        if constexpr (LAST) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) { dst[u] = dstn[u]; tof[u] = tofn[u]; }
+        }
+        ++m;
+    };
+    using std::true_type;
+    using std::false_type;
+    bool prev_tile = false;                         // the unit before this one was a tile (its output rows are waiting in LDS)
+#pragma unroll 1
+    while (cur.ri < S.nruns) {
+        const K6Iter nxt = k6_next(S, cur);
+        has_next = nxt.ri < S.nruns;
+        Tn = has_next ? k6_tile(S, nxt) : T;
+        rs2n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)Tn.b * img * p.C), 0, img_bytes, 0x00020000);
+        phase(true_type{}, false_type{}, 0, false);
+#pragma unroll 1
+        for (int k = 1; k < nch - 1; ++k) phase(false_type{}, false_type{}, k, k == 1 && prev_tile);
+        phase(false_type{}, true_type{}, nch - 1, nch == 2 && prev_tile);
+        prev_tile = !T.prime;
+        Tprev = T; T = Tn; rs2 = rs2n; cur = nxt;
+    }
+    __syncthreads();
+    __syncthreads();
+    store_tile(launder(tp), Tprev, true);          // the last unit of a workgroup is always a tile
+}
+
+static int device_cus()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_ACQUIRE);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELEASE);
+    }
+    return n;
+}
+
+template <bool HASFLOW, int NS>
+static int launch_wc6_ns(const WcParams &p, int nblk, hipStream_t st)
+{
+    static LdsAttr attr;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_v6_kernel<HASFLOW, NS>), K6_LDS)) return rc;
+    if (g_ev_start) {
+        hipExtLaunchKernelGGL((warp_corr_v6_kernel<HASFLOW, NS>), dim3(nblk), dim3(1024), K6_LDS, st, g_ev_start, g_ev_stop, 0, p);
+        g_ev_start = g_ev_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL((warp_corr_v6_kernel<HASFLOW, NS>), dim3(nblk), dim3(1024), K6_LDS, st, p);
+    }
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+template <bool HASFLOW>
+static int launch_wc6(WcParams p, hipStream_t st)
+{
+    PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
+    PIV_REQUIRE((size_t)p.B * p.H * p.W * 16 < 0x7fffffffull, "warp_corr: the flow of %d x %dx%d exceeds the 2 GiB buffer-descriptor range", p.B, p.H, p.W);
+    PIV_REQUIRE((size_t)p.B * p.Ho * p.Wo * OUTC * 4 < 0x7fffffffull, "warp_corr: the output of %d x %dx%d exceeds the 2 GiB buffer-descriptor range", p.B, p.Ho, p.Wo);
+    const int tiles_x = cdiv(p.Wo, TO), tiles_y = cdiv(p.Ho, TO);
+    const int slots = std::max(8, device_cus() / 8 * 8);          // one 16-wave workgroup per CU; a multiple of 8 keeps the XCD bands
+    // Run length: the sliding window needs chunk k of every tile in buffer k (two chunks: C = 64).  The longest power-of-two run
+    // that still leaves a run for every CU and spreads evenly (a run count that is a multiple of the CU count, or at least four
+    // runs per CU); a function of the launch's size only -- the bits of a value do not depend on it.
+    p.rl = 1;
+    if (p.C == 64 && !(PIV_KNOB(1) & 65536))
+        for (int rl = 2; rl <= tiles_y; rl *= 2) {
+            const long n = (long)tiles_x * cdiv(tiles_y, rl) * p.B;
+            if (n < slots) break;
+            if (n % slots == 0 || n >= 4L * slots) p.rl = rl;
+        }
+    const long nruns = (long)tiles_x * cdiv(tiles_y, p.rl) * p.B;
+    const int nblk = nruns <= slots ? (int)nruns : slots;
+    return p.rl > 1 ? launch_wc6_ns<HASFLOW, 2>(p, nblk, st) : launch_wc6_ns<HASFLOW, 4>(p, nblk, st);
+}
+
 static int wc_variant() { return PIV_KNOB(0); }
 
 int launch_warp_corr(const float *f1, const float *f2, const float *flow, float flow_scale, float *out,
@@ -824,7 +1357,7 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
     PIV_REQUIRE(f1 && f2 && out, "warp_corr: null pointer");
     PIV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "warp_corr: empty shape B=%d C=%d H=%d W=%d", B, C, H, W);
     PIV_REQUIRE(stride >= 1 && stride <= 4, "warp_corr: stride=%d unsupported", stride);
-    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, PIV_KNOB(2), 0,
+    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, PIV_KNOB(2), 0, 1,
                reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(10) << 32) | (unsigned)PIV_KNOB(9))};
     if (nhwc) {
         PIV_REQUIRE(C % 32 == 0, "warp_corr (channels-last): C=%d must be a multiple of 32", C);
@@ -835,13 +1368,15 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
             if (C % 64 == 0) return launch_wc<64, true>(p, st);
             return launch_wc<32, true>(p, st);
         }
-        // Shipped policy: up to two tiles per CU the launch is latency-bound -> v4 (a whole CU per tile, needs C % 64 == 0);
-        // beyond that throughput-bound -> v3 (512 threads, 128 VGPRs: two workgroups per CU overlap each other's phases).
+        // Shipped policy (round 4): v6 for every launch (persistent specialised waves; needs at least two 32-channel chunks).
+        if (variant == 0 && C >= 64) return flow ? launch_wc6<true>(p, st) : launch_wc6<false>(p, st);
+        // Rounds 1-3, kept for A/B measurements in the tools build: up to two tiles per CU v4 (a whole CU per tile, C % 64 == 0),
+        // beyond that v3 (512 threads, two workgroups per CU).  Their summation order differs from v6's.
         const long tiles = (long)cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * B;
-        if ((variant == 0 && C % 64 == 0 && tiles <= 512) || (variant == 5 && C % 64 == 0))
+        if (((variant == 0 || variant == 7) && C % 64 == 0 && tiles <= 512) || (variant == 5 && C % 64 == 0))
             return flow ? launch_wc4<true>(p, st) : launch_wc4<false>(p, st);
         if (variant == 4) return flow ? launch_wc3<true, false>(p, st) : launch_wc3<false, false>(p, st);     // A/B: one pixel per lane
-        if (variant == 0 || variant == 5 || variant == 6) return flow ? launch_wc3<true, true>(p, st) : launch_wc3<false, true>(p, st);
+        if (variant == 0 || variant == 5 || variant == 6 || variant == 7) return flow ? launch_wc3<true, true>(p, st) : launch_wc3<false, true>(p, st);
         PIV_REQUIRE(false, "warp_corr: unknown kernel variant %d", variant);
     }
     if (C % 64 == 0) return launch_wc<64, false>(p, st);
