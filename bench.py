@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -255,14 +256,25 @@ def l3_throughput_regime(dev, batch=8, launches=40):
         launch()
     b.record()
     torch.cuda.synchronize(dev)
-    t = a.elapsed_time(b) / launches * 1e-3
+    t_b2b = a.elapsed_time(b) / launches * 1e-3
+    # the kernel's own duration: the same launches back to back, every dispatch with its own start / stop events (what rocprofv3
+    # reports per kernel; the ~3 us between two dependent kernels of a stream belong to no kernel)
+    us = ctypes.c_double(0.0)
+    _lib.check(lib.pivlfn_warp_corr_nhwc_timed(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out.data_ptr(), batch, C, n, n, s, 1,
+                                               launches, ctypes.byref(us), st), "wc timed")
+    t = us.value * 1e-6
     alg = l3_algorithmic_bytes(batch, 1024, 1024, 3, C, s)
-    traffic, traffic_src = counter_traffic("r03_pmc_l3b8_warp_corr.json") if batch == 8 else (None, "no counter pass for this batch")
+    traffic, traffic_src = counter_traffic("r04_pmc_l3b8_warp_corr.json") if batch == 8 else (None, "no counter pass for this batch")
     return {"bound": "hbm", "achieved": round(alg / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / t / 8e12, 4),
             "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": round(t * 1e6, 2), "algorithmic_bytes_per_launch": alg, "launches_timed": launches,
-            "workload": f"level-3 warp+correlation of batch {batch} x 1024x1024 (C=64, stride 2, 2048 tiles), back-to-back launches "
-                        "(launch gaps included)"}
+            "avg_launch_us": round(t * 1e6, 2), "avg_back_to_back_us": round(t_b2b * 1e6, 2),
+            "frac_back_to_back": round(alg / t_b2b / 8e12, 4),
+            "algorithmic_bytes_per_launch": alg, "launches_timed": launches,
+            "kernel": "warp_corr_v6_kernel<true, 2> (persistent workgroups, sliding window over runs of 8 tiles)",
+            "timer": "avg_launch_us: HIP start/stop events attached to each of the back-to-back dispatches (hipExtLaunchKernelGGL, "
+                     "pivlfn_warp_corr_nhwc_timed) = the kernel duration rocprofv3 reports; avg_back_to_back_us: one event pair around all "
+                     "launches / launches (adds the ~3 us gap between dependent kernels of a stream; rounds 1-3 quoted this figure)",
+            "workload": f"level-3 warp+correlation of batch {batch} x 1024x1024 (C=64, stride 2, 2048 tiles), back-to-back launches"}
 
 
 def main():
@@ -378,10 +390,10 @@ def main():
             t_k = k_ms / k_n * 1e-3                       # start/stop events attached to the dispatch itself
             t_pair = k_empty_ms / k_n * 1e-3              # plain hipEventRecord pair around the same launch (incl. marker cost)
             ach = alg / t_k / 1e9
-            traffic, traffic_src = (counter_traffic("r03_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
+            traffic, traffic_src = (counter_traffic("r04_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
                                     else (None, "no counter pass for this workload"))
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": f"warp_corr_kernel (level {L}: C={C}, stride {stride})",
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": f"{'warp_corr_v7_kernel (one tile per CU)' if (C % 64 == 0 and B * (S // (2 ** (L - 1)) // stride // 8) ** 2 <= 256) else 'warp_corr_v6_kernel (persistent)'} (level {L}: C={C}, stride {stride})",
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(t_k * 1e6, 2), "launches_timed": k_n,
                     "event_record_pair_us": round(t_pair * 1e6, 2),
                     "timer": "HIP start/stop events attached to the dispatch (hipExtLaunchKernelGGL) in every timed step, on the "
@@ -415,10 +427,10 @@ def main():
         if l1 is not None and l1[2]:
             alg1 = l3_algorithmic_bytes(B, S, S, 1, 64, 2)
             t1 = l1[0] / l1[2] * 1e-3
-            tr1, src1 = counter_traffic("r03_pmc_l1_warp_corr.json") if B == 1 else (None, "no counter pass for this workload")
+            tr1, src1 = counter_traffic("r04_pmc_l1_warp_corr.json") if B == 1 else (None, "no counter pass for this workload")
             out["roofline_level1"] = {"bound": "hbm", "achieved": round(alg1 / t1 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                       "frac": round(alg1 / t1 / 8e12, 4), "traffic": tr1, "traffic_source": src1,
-                                      "kernel": "warp_corr_kernel (level 1: C=64, stride 2; 395 MB per launch, beyond the Infinity Cache)",
+                                      "kernel": "warp_corr_v6_kernel<true, 2> (level 1: C=64, stride 2; 395 MB per launch, beyond the Infinity Cache; runs of 16 tiles)",
                                       "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2]}
         if world == 1 and args.model == "piv" and S == 1024 and not args.lean:
             out["roofline_batch8"] = l3_throughput_regime(dev)

@@ -35,6 +35,8 @@ typedef struct {
 } pivlfn_tensor;
 
 const char *pivlfn_last_error(void);
+/* ABI version.  2 (round 4): + pivlfn_warp_corr_nhwc_timed; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
+ * (added in round 3 without a bump).  No entry point of version 1 changed its signature or meaning. */
 int         pivlfn_abi_version(void);
 
 /* The library keeps no process-global mutable state: entry points may be called concurrently from several threads, on
@@ -72,6 +74,13 @@ int pivlfn_warp_corr_fwd(const float *first, const float *second, const float *f
  * or NULL; out: [B,Ho,Wo,56] (49 displacements + 7 zero lanes). C must be a multiple of 32. */
 int pivlfn_warp_corr_nhwc(const float *first, const float *second, const float *flow, float flow_scale,
                           float *out, int B, int C, int H, int W, int stride, int leaky, void *stream);
+
+/* ---- measurement hook: `launches` (1..256) back-to-back launches of pivlfn_warp_corr_nhwc on `stream`, each dispatch carrying
+ * its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, the figure rocprofv3 reports per
+ * kernel -- no inter-kernel gap, no marker packets).  Synchronises the stream; *us_dispatch = mean microseconds per dispatch. */
+int pivlfn_warp_corr_nhwc_timed(const float *first, const float *second, const float *flow, float flow_scale,
+                                float *out, int B, int C, int H, int W, int stride, int leaky, int launches,
+                                double *us_dispatch, void *stream);
 
 /* ---- bilinear resize, align_corners=False, NCHW -> NCHW, with a per-channel multiplier
  * (mul[c % 2] when mul != NULL, host pointer to 2 floats): the two interpolate calls and the flow
@@ -122,8 +131,8 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
 #define PIVLFN_PRECISION_F32_SPLIT 2
 /* PIVLFN_PRECISION_F32_SPLIT3: the same with two pieces per operand and the three leading partial products (h.h, h.m, m.h):
  * a product carries a relative error of at most 2^-21 (typically 2^-23.5, about one fp32 ulp on each operand); measured against
- * float64 the layer outputs are as accurate as SPLIT's and more accurate than the fp32 instruction's (fewer roundings in the
- * accumulation), at half the matrix work.  Applies to the residual-free convolutions with an output grid of at least 64 x 64 per
+ * float64 the layer outputs' mean error stays within 2 x the fp32 instruction's (what tests/test_gpu_split.py asserts; on the layers
+ * measured there it was lower: the fp16 instruction rounds once per 16 products), at half the matrix work of SPLIT.  Applies to the residual-free convolutions with an output grid of at least 64 x 64 per
  * image: stride 1 (4-row tiles and split-K on the small grids) and 3 x 3 stride 2.  Opt-in (not the default): the multiplicands
  * are 22-23 bits wide, one fewer than fp32's. */
 #define PIVLFN_PRECISION_F32_SPLIT3 3

@@ -65,7 +65,7 @@ using namespace pivlfn;
 extern "C" {
 
 const char *pivlfn_last_error(void) { return g_err; }
-int pivlfn_abi_version(void) { return 1; }
+int pivlfn_abi_version(void) { return 2; }
 
 #ifdef PIVLFN_TOOLS
 int pivlfn_tune(int knob, int value)
@@ -173,6 +173,32 @@ int pivlfn_set_precision(pivlfn_net *net, int precision) { return net_set_precis
 int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W, void *stream)
 {
     return conv_head_forward(conv, x, res4, out4, B, H, W, (hipStream_t)stream);
+}
+
+int pivlfn_warp_corr_nhwc_timed(const float *first, const float *second, const float *flow, float flow_scale, float *out,
+                                int B, int C, int H, int W, int stride, int leaky, int launches, double *us_dispatch, void *stream)
+{
+    PIV_REQUIRE(launches >= 1 && launches <= 256 && us_dispatch, "warp_corr_nhwc_timed: launches=%d must be 1..256, us_dispatch non-null", launches);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)launches, nullptr);
+    int rc = PIVLFN_OK;
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); rc = PIVLFN_ERR_HIP; break; }
+    for (int i = 0; rc == PIVLFN_OK && i < launches; ++i) {      // back to back: every dispatch carries its own start / stop events
+        warp_corr_time_next(ev[2 * i], ev[2 * i + 1]);
+        rc = launch_warp_corr(first, second, flow, flow_scale, out, B, C, H, W, stride, leaky, true, st);
+    }
+    warp_corr_time_next(nullptr, nullptr);
+    double total = 0.0;
+    if (rc == PIVLFN_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("hipStreamSynchronize failed"); rc = PIVLFN_ERR_HIP; }
+    for (int i = 0; rc == PIVLFN_OK && i < launches; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) { set_error("hipEventElapsedTime failed"); rc = PIVLFN_ERR_HIP; break; }
+        total += ms;
+    }
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (rc == PIVLFN_OK) *us_dispatch = total * 1e3 / launches;
+    return rc;
 }
 
 int pivlfn_profile_enable(pivlfn_net *net, int level) { return net_profile_enable(net, level); }

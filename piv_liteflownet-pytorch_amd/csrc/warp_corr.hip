@@ -942,6 +942,91 @@ __device__ __forceinline__ f32x4 k6_blend(const f32x4 w, const f32x4 (&x)[NT])
     else return w[0] * x[0];
 }
 
+// Dot products of one consumer lane over NPL 16-channel planes (v6: the two planes of a chunk; v7: the four of a 64-channel group).
+// Lane = (tile half h, column j, channel quad g) of displacement column dx: 4 output rows x 7 displacement rows = 28 accumulators,
+// kept as pairs for v_pk_fma_f32: one read of the warped tile at row r feeds output rows yy and yy + 1 of a row pair (dy = r - yy
+// and r - yy - 1), the f1 values of the two rows sit side by side in a register pair (the f1 tile is stored interleaved that way),
+// the warped value is broadcast: P0[i] = {acc[0][i + 1], acc[1][i]}, P1[i] = {acc[2][i + 1], acc[3][i]}; the four displacements
+// without a partner (acc[0][0], acc[1][6], acc[2][0], acc[3][6]) stay scalar.  Every accumulator is one fmaf chain over its
+// channels in ascending order.  64 instructions and 14 LDS reads per plane.  The reads roll five rows ahead of the multiplies,
+// across planes (a register is refilled right after its last use), the next plane's f1 quads arrive half a plane early -- with
+// one row ahead the phase was bound by LDS latency (measured: 4000 cycles for 128 instructions in the first v7).
+struct K6Acc { f32x2 P0[6], P1[6]; float s0, s1, s2, s3; };
+__device__ __forceinline__ void k6_acc_zero(K6Acc &A)
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { A.P0[i] = f32x2{0.f, 0.f}; A.P1[i] = f32x2{0.f, 0.f}; }
+    A.s0 = A.s1 = A.s2 = A.s3 = 0.f;
+}
+// f1 quads of plane pl: lds + f1a + pl * F1S + {0, 512, 1024, 1536} (row pair 2h halves 0, 1; row pair 2h + 1 halves 0, 1);
+// warped row r of plane pl: lds + row[r] + pl * PLS (row: anything indexable -- an array of ring rows in v6, base + r * pitch in v7).
+template <int NPL, int F1S, int PLS, class RowAddr>
+__device__ __forceinline__ void k6_dots(const char *lds, unsigned f1a, const RowAddr &row, K6Acc &A)
+{
+    constexpr int D = 5;                   // rows in flight ahead of the multiplies (10 % D == 0: register r % D serves rows r, r + D)
+    f32x4 R[D], F[4], Fn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F[i] = *reinterpret_cast<const f32x4 *>(lds + f1a + i * 512);
+#pragma unroll
+    for (int i = 0; i < D; ++i) R[i] = *reinterpret_cast<const f32x4 *>(lds + row[i]);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+        const f32x2 FA[4] = {f32x2{F[0][0], F[0][1]}, f32x2{F[0][2], F[0][3]}, f32x2{F[1][0], F[1][1]}, f32x2{F[1][2], F[1][3]}};
+        const f32x2 FB[4] = {f32x2{F[2][0], F[2][1]}, f32x2{F[2][2], F[2][3]}, f32x2{F[3][0], F[3][1]}, f32x2{F[3][2], F[3][3]}};
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const f32x4 v = R[r % D];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 vv = f32x2{v[e], v[e]};
+                if (r == 0) A.s0 = fmaf(FA[e][0], v[e], A.s0);
+                if (r >= 1 && r <= 6) A.P0[r - 1] = __builtin_elementwise_fma(FA[e], vv, A.P0[r - 1]);
+                if (r == 7) A.s1 = fmaf(FA[e][1], v[e], A.s1);
+                if (r == 2) A.s2 = fmaf(FB[e][0], v[e], A.s2);
+                if (r >= 3 && r <= 8) A.P1[r - 3] = __builtin_elementwise_fma(FB[e], vv, A.P1[r - 3]);
+                if (r == 9) A.s3 = fmaf(FB[e][1], v[e], A.s3);
+            }
+            // refill this register with the row D further on (this plane's, or the next plane's); the next plane's f1 quads half-way
+            if (r + D < 10) R[r % D] = *reinterpret_cast<const f32x4 *>(lds + row[r + D] + pl * PLS);
+            else if (pl + 1 < NPL) R[r % D] = *reinterpret_cast<const f32x4 *>(lds + row[r + D - 10] + (pl + 1) * PLS);
+            if (r == 4 && pl + 1 < NPL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Fn[i] = *reinterpret_cast<const f32x4 *>(lds + f1a + (pl + 1) * F1S + i * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (pl + 1 < NPL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) F[i] = Fn[i];
+        }
+    }
+}
+// The 28 sums of a lane as acc[yy * 7 + dy], then (S_0 + S_1) + (S_2 + S_3) over the four quad lanes as a reduce-scatter: after the
+// two steps lane g holds the 7 displacement rows dy of output row yy = 2 (g & 1) + (g >> 1) of its half.
+__device__ __forceinline__ void k6_reduce(const K6Acc &A, int lane, float (&r2)[7])
+{
+    float acc[28];
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy) {
+        acc[dy] = dy == 0 ? A.s0 : A.P0[dy > 0 ? dy - 1 : 0][0];
+        acc[7 + dy] = dy == 6 ? A.s1 : A.P0[dy < 6 ? dy : 0][1];
+        acc[14 + dy] = dy == 0 ? A.s2 : A.P1[dy > 0 ? dy - 1 : 0][0];
+        acc[21 + dy] = dy == 6 ? A.s3 : A.P1[dy < 6 ? dy : 0][1];
+    }
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float r1[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const float mine = b0 ? acc[14 + i] : acc[i], send = b0 ? acc[i] : acc[14 + i];
+        r1[i] = mine + dpp_xor1(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float mine = b1 ? r1[7 + i] : r1[i], send = b1 ? r1[i] : r1[7 + i];
+        r2[i] = mine + dpp_xor2(send);
+    }
+}
+
 // Tools build: lane 0 of one wave per role (0 consumer wave 0, 1 helper, 2 producer wave 8, 3 producer wave 15) stamps s_memtime
 // at three points of every step (after the barrier, after its first wait, at the end of its work): 96 stamps per role and workgroup.
 #ifdef PIVLFN_STAMPS
@@ -993,18 +1078,9 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
         const int dx = wave;
         const int g = lane & 3, j = (lane >> 2) & 7, h = lane >> 5;
         const unsigned a0 = (unsigned)((j + dx) * 64 + g * 16);
-        const unsigned f0 = (unsigned)(K6_F1OFF + (4 * h * 8 + j) * 64 + g * 16);
         const float cf = (float)p.C, cinv = pow2_reciprocal(p.C);
-        // Accumulators as pairs for v_pk_fma_f32: one read of the warped tile at row r feeds output rows yy and yy + 1 of a row pair
-        // (displacements dy = r - yy and r - yy - 1), with the f1 values of the two rows side by side in a register pair (the
-        // helper stores the f1 tile interleaved that way) and the warped value broadcast: P0[i] = {acc[0][i + 1], acc[1][i]},
-        // P1[i] = {acc[2][i + 1], acc[3][i]}; the four displacements without a partner (acc[0][0], acc[1][6], acc[2][0], acc[3][6])
-        // stay scalar.  Every accumulator is still one fmaf chain over its channels in ascending order: same bits, 64 instructions
-        // per 16-channel plane instead of 112.
-        f32x2 P0[6], P1[6];
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { P0[i] = f32x2{0.f, 0.f}; P1[i] = f32x2{0.f, 0.f}; }
+        K6Acc A;
+        k6_acc_zero(A);
         const unsigned fp0 = (unsigned)(K6_F1OFF + (4 * h) * 512 + (j * 4 + g) * 16);      // row pair 2h: + half * 512; row pair 2h + 1: + 1024
         int m = 0;
 #pragma unroll 1
@@ -1020,62 +1096,16 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
                 if (wave == 0) K6_STAMP(0, 3 * m);
                 const unsigned bo = (m & 1) ? (unsigned)K6_BUF : 0u;
                 if (work && !(p.dbg & 1)) {
-                    const char *f1b = lds + fp0 + bo;
+                    unsigned row[10];
 #pragma unroll
-                    for (int sub = 0; sub < 2; ++sub) {
-                        f32x2 FA[4], FB[4];       // {f1 row 0, row 1}[e], {row 2, row 3}[e] of this lane's half, e = 0..3
-#pragma unroll
-                        for (int hf = 0; hf < 2; ++hf) {
-                            const f32x4 qa = *reinterpret_cast<const f32x4 *>(f1b + sub * K6_F1PLANE + hf * 512);
-                            const f32x4 qb = *reinterpret_cast<const f32x4 *>(f1b + sub * K6_F1PLANE + 1024 + hf * 512);
-                            FA[2 * hf] = f32x2{qa[0], qa[1]}; FA[2 * hf + 1] = f32x2{qa[2], qa[3]};
-                            FB[2 * hf] = f32x2{qb[0], qb[1]}; FB[2 * hf + 1] = f32x2{qb[2], qb[3]};
-                        }
-                        f32x4 vq[2];              // row r + 1 is read before row r is used
-                        vq[0] = *reinterpret_cast<const f32x4 *>(lds + (rowoff[0] + bo) + sub * K6_PLANE);
-#pragma unroll
-                        for (int r = 0; r < 10; ++r) {
-                            if (r < 9) vq[(r + 1) & 1] = *reinterpret_cast<const f32x4 *>(lds + (rowoff[r + 1] + bo) + sub * K6_PLANE);
-                            __builtin_amdgcn_sched_barrier(0);
-                            const f32x4 v = vq[r & 1];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const f32x2 vv = f32x2{v[e], v[e]};
-                                if (r == 0) s0 = fmaf(FA[e][0], v[e], s0);
-                                if (r >= 1 && r <= 6) P0[r - 1] = __builtin_elementwise_fma(FA[e], vv, P0[r - 1]);
-                                if (r == 7) s1 = fmaf(FA[e][1], v[e], s1);
-                                if (r == 2) s2 = fmaf(FB[e][0], v[e], s2);
-                                if (r >= 3 && r <= 8) P1[r - 3] = __builtin_elementwise_fma(FB[e], vv, P1[r - 3]);
-                                if (r == 9) s3 = fmaf(FB[e][1], v[e], s3);
-                            }
-                        }
-                    }
+                    for (int r = 0; r < 10; ++r) row[r] = rowoff[r] + bo;
+                    k6_dots<2, K6_F1PLANE, K6_PLANE>(lds, fp0 + bo, row, A);
                 }
                 if (wave == 0) K6_STAMP(0, 3 * m + 1);
             }
-            float acc[28];                // acc[yy * 7 + dy]
-#pragma unroll
-            for (int dy = 0; dy < 7; ++dy) {
-                acc[dy] = dy == 0 ? s0 : P0[dy > 0 ? dy - 1 : 0][0];
-                acc[7 + dy] = dy == 6 ? s1 : P0[dy < 6 ? dy : 0][1];
-                acc[14 + dy] = dy == 0 ? s2 : P1[dy > 0 ? dy - 1 : 0][0];
-                acc[21 + dy] = dy == 6 ? s3 : P1[dy < 6 ? dy : 0][1];
-            }
             if (!work) continue;
-            // tile done: (S_0 + S_1) + (S_2 + S_3) over the four quad lanes as a reduce-scatter -- after the two steps lane g holds
-            // the 7 displacement rows dy of output row yy = 2 (g & 1) + (g >> 1) of its half
-            const bool b0 = lane & 1, b1 = lane & 2;
-            float r1[14], r2[7];
-#pragma unroll
-            for (int i = 0; i < 14; ++i) {
-                const float mine = b0 ? acc[14 + i] : acc[i], send = b0 ? acc[i] : acc[14 + i];
-                r1[i] = mine + dpp_xor1(send);
-            }
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const float mine = b1 ? r1[7 + i] : r1[i], send = b1 ? r1[i] : r1[7 + i];
-                r2[i] = mine + dpp_xor2(send);
-            }
+            float r2[7];
+            k6_reduce(A, lane, r2);
             const int yy = 2 * (lane & 1) + ((lane >> 1) & 1);
             float *tr = reinterpret_cast<float *>(lds + K6_TR) + ((4 * h + yy) * 8 + j) * OUTC + dx;
 #pragma unroll
@@ -1084,9 +1114,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
                 if (p.leaky) v = lrelu01(v);
                 tr[7 * dy] = v;
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { P0[i] = f32x2{0.f, 0.f}; P1[i] = f32x2{0.f, 0.f}; }
-            s0 = s1 = s2 = s3 = 0.f;
+            k6_acc_zero(A);
         }
         __syncthreads();
         return;
@@ -1349,6 +1377,181 @@ static int launch_wc6(WcParams p, hipStream_t st)
     return p.rl > 1 ? launch_wc6_ns<HASFLOW, 2>(p, nblk, st) : launch_wc6_ns<HASFLOW, 4>(p, nblk, st);
 }
 
+// ---- v7: latency kernel (round 4): one tile per CU, every gather of the tile in flight at once -------------------------------
+// For launches with at most one tile per CU (level 3 of a 1024x1024 pair: 256 tiles) there is nothing to pipeline against: the
+// launch is a chain flow -> taps -> gathers -> blend -> dot products -> reduce / transpose -> store on every CU at once.  v7 is
+// v4's structure with the pieces round 4 measured to matter:
+//   * taps per wave: the 16 positions a wave gathers are computed by its lanes 0..15 and handed over through its own entries of
+//     an LDS table -- no workgroup barrier between the flow read and the gathers;
+//   * dot products as in v6 (k6_dots: columns of rows, v_pk_fma_f32 on row pairs, rolling LDS reads) on 7 waves -- 256 vector
+//     instructions and 56 LDS reads per 64 channels and lane where v4 spent 4700-5000 cycles on LDS-bound reads (14 waves with two
+//     rows per lane need 40 % more LDS bytes and were LDS-bound at twice the time);
+//   * output transpose channel-major with an odd pitch: conflict-free stores (v4 / v6: 8-way conflicts on 7 stores per lane).
+// Summation order = v6's (four quad-lane chains over 16-channel planes ascending, (S_0 + S_1) + (S_2 + S_3), blend_taps for
+// every position): a level's bits do not depend on which of the two kernels its launch size selects.
+constexpr int K7_PLANE = NPOS * 64 + 64;                   // one 16-channel plane of the warped tile
+constexpr int K7_F1OFF = 4 * K7_PLANE;
+constexpr int K7_TAPS = K7_F1OFF + 4 * K6_F1PLANE;
+constexpr int K7_TR = K7_TAPS + NPOS * 32;                 // output tile [49 channels][65] floats
+constexpr int K7_TRP = 65;
+constexpr int K7_LDS = K7_TR + 49 * K7_TRP * 4 + 60;       // 86160 -> rounded below
+
+template <bool HASFLOW>
+__global__ __launch_bounds__(1024) void warp_corr_v7_kernel(const WcParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+    constexpr int NT = HASFLOW ? 4 : 1;
+    const int tiles_x = (p.Wo + TO - 1) / TO, tiles_y = (p.Ho + TO - 1) / TO;
+    int bid = xcd_remap(blockIdx.x, tiles_x * tiles_y * p.B);
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, b = bid / tiles_y;
+    const int ox0 = tx * TO, oy0 = ty * TO;
+    if (p.dbg & 8) return;
+    WC_STAMP_DECL;
+    WC_STAMP();                                   // 0: entry
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t img = (size_t)p.H * p.W;
+    const unsigned img_bytes = (unsigned)(img * p.C * sizeof(float));
+    const unsigned pix_bytes = (unsigned)p.C * 4u;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.flow ? p.flow : p.f1), 0,
+                                                                         p.flow ? (unsigned)((size_t)p.B * img * 16) : 0u, 0x00020000);
+
+    // f1: threads 0..511 own (row pair rp, column, quad): rows 2 rp and 2 rp + 1 of the tile -- independent of the flow, issued first
+    const int q16 = tid & 15;
+    const int frp = tid >> 7, fcol = (tid >> 4) & 7;
+    unsigned f1o = OOB;
+    if (tid < 512 && ox0 + fcol < p.Wo) f1o = (unsigned)(((oy0 + 2 * frp) * p.s) * p.W + (ox0 + fcol) * p.s) * pix_bytes + 16u * q16;
+    const unsigned f1row = (unsigned)(p.s * p.W) * pix_bytes;
+    const bool f1a = f1o != OOB && oy0 + 2 * frp < p.Ho, f1b_ok = f1o != OOB && oy0 + 2 * frp + 1 < p.Ho;
+    f32x4 fa = bload_s(rs1, f1a ? f1o : OOB, 0), fb = bload_s(rs1, f1b_ok ? f1o + f1row : OOB, 0);
+
+    // taps of the 16 positions this wave gathers (item u of a thread: position (tid >> 4) + 64 u = 4 wave + (lane >> 4) + 64 u)
+    {
+        const int l16 = lane & 15;
+        const int pos = 64 * (l16 >> 2) + 4 * wave + (l16 & 3), pp = min(pos, NPOS - 1);
+        const int iy = (oy0 + pp / TP - 3) * p.s, ix = (ox0 + pp % TP - 3) * p.s;
+        float2 uv = {0.f, 0.f};
+        if (HASFLOW) uv = k6_flow(p, rsf, b, iy, ix);
+        i32x4 o; f32x4 w;
+        k6_taps<HASFLOW>(p, pix_bytes, iy, ix, uv, o, w);
+        if (pos < NPOS) {
+            *reinterpret_cast<i32x4 *>(lds + K7_TAPS + pp * 32) = o;
+            *reinterpret_cast<f32x4 *>(lds + K7_TAPS + pp * 32 + 16) = w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave reads back its own entries below
+    }
+    WC_STAMP();                                   // 1: flow read, taps in the table
+    WC_STAMP();                                   // 2: (no barrier here)
+    const int pq = tid >> 4;                       // item u: position pq + 64 u; u = 3 exists for pq < 4 (wave 0)
+    const bool has3 = wave == 0;
+
+    // consumers: waves 0..6 = displacement column dx, lane = (tile half h, column j, quad g)
+    const int dx = wave;
+    const int g = lane & 3, j = (lane >> 2) & 7, h = lane >> 5;
+    K6Acc A;
+    k6_acc_zero(A);
+
+#pragma unroll 1
+    for (int c0 = 0; c0 < p.C; c0 += 64) {
+        f32x4 x[4][NT];
+        const int soff = c0 * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < 3 || has3) {
+                const int pos = min(pq + 64 * u, NPOS - 1);
+                const i32x4 o = *reinterpret_cast<const i32x4 *>(lds + K7_TAPS + pos * 32);
+                const bool ok = (pq + 64 * u < NPOS) & !(p.dbg & 2);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) x[u][k] = bload_s(rs2, ok ? (unsigned)o[k] + 16u * q16 : OOB, soff);
+            }
+        }
+        WC_STAMP();                                   // 3: gathers issued
+        if (c0) {
+            fa = bload_s(rs1, f1a ? f1o : OOB, soff);
+            fb = bload_s(rs1, f1b_ok ? f1o + f1row : OOB, soff);
+            __syncthreads();              // the previous 64 channels' dot products are done with the LDS image
+        }
+        int tl = tid;
+        asm volatile("" : "+v"(tl));               // LDS addresses of the blend are rebuilt here rather than kept (spilled) across the gathers
+        const int q16l = tl & 15, pql = tl >> 4;
+        const unsigned wq = (unsigned)((q16l >> 2) * K7_PLANE + (q16l & 3) * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((u < 3 || has3) && pql + 64 * u < NPOS) {      // weights from the table again: 16 registers fewer across the gathers
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(lds + K7_TAPS + (pql + 64 * u) * 32 + 16);
+                *reinterpret_cast<f32x4 *>(lds + wq + (pql + 64 * u) * 64) = k6_blend<NT>(w, x[u]);
+            }
+        if (tl < 512) {
+            char *fd = lds + K7_F1OFF + (q16l >> 2) * K6_F1PLANE + ((tl >> 7) * 2) * 512 + (((tl >> 4) & 7) * 4 + (q16l & 3)) * 16;
+            *reinterpret_cast<f32x4 *>(fd) = f32x4{fa[0], fb[0], fa[1], fb[1]};
+            *reinterpret_cast<f32x4 *>(fd + 512) = f32x4{fa[2], fb[2], fa[3], fb[3]};
+        }
+        WC_STAMP();                                   // 4: gathers arrived, blended, in LDS
+        __syncthreads();
+        WC_STAMP();                                   // 5: barrier passed
+        if (wave < 7 && !(p.dbg & 1)) {
+            int ll = lane;
+            asm volatile("" : "+v"(ll));           // the ten row addresses are built here, not kept across the gathers
+            const int g_ = ll & 3, j_ = (ll >> 2) & 7, h_ = ll >> 5;
+            struct { unsigned base; __device__ unsigned operator[](int r) const { return base + r * (TP * 64); } } row{(unsigned)((4 * h_ * TP + j_ + dx) * 64 + g_ * 16)};
+            k6_dots<4, K6_F1PLANE, K7_PLANE>(lds, (unsigned)(K7_F1OFF + (4 * h_) * 512 + (j_ * 4 + g_) * 16), row, A);
+        }
+    }
+
+    WC_STAMP();                                   // 6: dot products done
+    // reduce over the four quad lanes, then the output tile channel-major with an odd pitch: the 64 lanes of a store are 64 pixels
+    float *tr = reinterpret_cast<float *>(lds + K7_TR);
+    if (wave < 7) {
+        const float cf = (float)p.C, cinv = pow2_reciprocal(p.C);
+        float r2[7];
+        k6_reduce(A, lane, r2);
+        const int px = (4 * h + 2 * (lane & 1) + ((lane >> 1) & 1)) * 8 + j;
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy) {
+            float v = mean_over_c(r2[dy], cf, cinv);
+            if (p.leaky) v = lrelu01(v);
+            tr[(7 * dy + dx) * K7_TRP + px] = v;
+        }
+    }
+    WC_STAMP();                                   // 7: reduced, transposed
+    __syncthreads();
+    WC_STAMP();                                   // 8: barrier passed
+    if (tid < 64 * (OUTC / 4) && !(p.dbg & 4)) {
+        const int px = tid / (OUTC / 4), q = tid - px * (OUTC / 4);
+        const int oy = oy0 + (px >> 3), ox = ox0 + (px & 7);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 4 * q + e < 49 ? tr[min(4 * q + e, 48) * K7_TRP + px] : 0.f;
+        if (oy < p.Ho && ox < p.Wo) *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) = v;
+    }
+    WC_STAMP();                                   // 9: stores issued
+    WC_STAMP_FLUSH();
+}
+
+template <bool HASFLOW>
+static int launch_wc7(const WcParams &p, hipStream_t st)
+{
+    PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
+    PIV_REQUIRE((size_t)p.B * p.H * p.W * 16 < 0x7fffffffull, "warp_corr: the flow of %d x %dx%d exceeds the 2 GiB buffer-descriptor range", p.B, p.H, p.W);
+    static LdsAttr attr;
+    const int ldsb = (K7_LDS + 255) / 256 * 256;
+    if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_v7_kernel<HASFLOW>), ldsb)) return rc;
+    const int nblk = cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * p.B;
+    if (g_ev_start) {
+        hipExtLaunchKernelGGL((warp_corr_v7_kernel<HASFLOW>), dim3(nblk), dim3(1024), ldsb, st, g_ev_start, g_ev_stop, 0, p);
+        g_ev_start = g_ev_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL((warp_corr_v7_kernel<HASFLOW>), dim3(nblk), dim3(1024), ldsb, st, p);
+    }
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
 static int wc_variant() { return PIV_KNOB(0); }
 
 int launch_warp_corr(const float *f1, const float *f2, const float *flow, float flow_scale, float *out,
@@ -1368,8 +1571,14 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
             if (C % 64 == 0) return launch_wc<64, true>(p, st);
             return launch_wc<32, true>(p, st);
         }
-        // Shipped policy (round 4): v6 for every launch (persistent specialised waves; needs at least two 32-channel chunks).
-        if (variant == 0 && C >= 64) return flow ? launch_wc6<true>(p, st) : launch_wc6<false>(p, st);
+        // Shipped policy (round 4): at most one tile per CU and whole 64-channel groups -> v7 (latency kernel); otherwise v6
+        // (persistent specialised waves; needs at least two 32-channel chunks).  Both sum in one order.
+        const long tiles6 = (long)cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * B;
+        if ((variant == 0 && C % 64 == 0 && tiles6 <= device_cus()) || variant == 8) {
+            PIV_REQUIRE(C % 64 == 0, "warp_corr v7: C=%d must be a multiple of 64", C);
+            return flow ? launch_wc7<true>(p, st) : launch_wc7<false>(p, st);
+        }
+        if ((variant == 0 || variant == 9) && C >= 64) return flow ? launch_wc6<true>(p, st) : launch_wc6<false>(p, st);
         // Rounds 1-3, kept for A/B measurements in the tools build: up to two tiles per CU v4 (a whole CU per tile, C % 64 == 0),
         // beyond that v3 (512 threads, two workgroups per CU).  Their summation order differs from v6's.
         const long tiles = (long)cdiv(p.Wo, TO) * cdiv(p.Ho, TO) * B;

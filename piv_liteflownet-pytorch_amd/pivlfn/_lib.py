@@ -28,6 +28,8 @@ SIGNATURES = {
     "pivlfn_backwarp": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "pivlfn_warp_corr_fwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
     "pivlfn_warp_corr_nhwc": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
+    "pivlfn_warp_corr_nhwc_timed": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_void_p] + [ctypes.c_int] * 7
+                                    + [ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]),
     "pivlfn_resize_bilinear": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 6 + [c_float_p, ctypes.c_void_p]),
     "pivlfn_create": (ctypes.c_int, [ctypes.POINTER(Tensor), ctypes.c_int, ctypes.c_float, ctypes.c_int, c_float_p, ctypes.POINTER(ctypes.c_void_p)]),
     "pivlfn_destroy": (ctypes.c_int, [ctypes.c_void_p]),

@@ -62,7 +62,7 @@ parser.add_argument("--weights", type=str, default=None, help="state dict file (
 parser.add_argument("--synthetic_weights", action="store_true")
 parser.add_argument("--batch", type=int, default=4, help="pairs per forward")
 parser.add_argument("--precision", type=str, default=None, choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"],
-                    help="how the large convolutions multiply (not a reference flag; default: the library's, fp32_split3 -- "
+                    help="how the large convolutions multiply (not a reference flag; default: the library's, fp32 -- "
                          "see Network.precision)")
 
 

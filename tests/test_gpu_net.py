@@ -205,6 +205,20 @@ def test_full_size_1024_properties(nets, dev):
     assert f.abs().max().item() > 1.0
 
 
+def test_full_size_1024_vs_oracle(nets, dev):
+    """BASELINE configs[1] itself against the CPU oracle (one pair, ~10 s of CPU): the headline size takes the level-1 / level-2
+    sliding-window warp+correlation launches, the one-tile-per-CU launch of level 3 and every full-occupancy convolution shape
+    inside one forward; same tolerance as the golden cases."""
+    a, b = synth.particle_batch(1, 1024, 1024, seed=1234)
+    i1, i2 = torch.from_numpy(a), torch.from_numpy(b)
+    onet = orc.make_net("piv", synth.generate_weights("piv", 0), corr="c")
+    with torch.no_grad():
+        want = onet.forward(i1, i2).numpy()
+    got = nets["piv"](i1.to(dev), i2.to(dev)).cpu().numpy()
+    assert np.abs(want).max() > 1.0
+    _check(got, want, "piv 1x1024x1024 vs oracle")
+
+
 def test_run_py_end_to_end(tmp_path, dev):
     """run.py counterpart: a 6-frame sequence (5 pairs, 3 batches through the copy-stream pipeline) -> .flo files equal to
     estimate() on the same pairs."""

@@ -19,7 +19,7 @@ def rel(a, b):
 
 def test_native_library_is_the_one_loaded(dev):
     lib = _lib.load()
-    assert lib.pivlfn_abi_version() == 1
+    assert lib.pivlfn_abi_version() == 2
     assert "libpivlfn.so" in open("/proc/self/maps").read()
 
 
@@ -127,6 +127,73 @@ def test_fused_warp_correlation_vs_oracle_composition(shape, nhwc, dev):
     got = _fused(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev),
                  torch.from_numpy(fl).to(dev) if warp else None, scale, s, 1, dev, nhwc).cpu().numpy()
     assert rel(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [
+    (4, 64, 256, 256, 2, True),      # 1024 tiles: persistent kernel, sliding window over runs of 4 tiles (two items per lane)
+    (3, 64, 200, 136, 2, True),      # 13 x 9 x 3 tiles: runs of 2 with a ragged last run, ragged tiles right and bottom, several runs per workgroup
+    (1, 64, 512, 520, 2, True),      # 32 x 33 tiles: wide image, runs that do not divide the tile rows
+    (1, 96, 128, 128, 1, True),      # 256 tiles, C not a multiple of 64: persistent kernel without the window, three chunks
+    (2, 128, 96, 160, 1, True),      # 480 tiles, four chunks
+    (1, 64, 128, 128, 2, True),      # 64 tiles: the one-tile-per-CU kernel
+    (1, 128, 56, 72, 1, True),       # 63 tiles of two 64-channel groups
+    (1, 192, 32, 32, 1, False),      # level-6 shape: no flow, three groups
+    (2, 64, 96, 40, 2, False),       # no flow on the persistent path
+])
+def test_channels_last_kernels_vs_oracle_at_launch_sizes(shape, dev):
+    """The channels-last kernels pivlfn_forward launches, at sizes where their launch policy takes each of its branches (round 4:
+    latency kernel, persistent kernel with and without the sliding window), against the oracle's backwarp + correlation; large,
+    smooth-plus-noise flows so that taps leave the image on every side."""
+    B, C, H, W, s, warp = shape
+    g = np.random.default_rng(100 + C + H + B)
+    f1 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    f2 = g.standard_normal((B, C, H, W)).astype(np.float32)
+    fl = None
+    if warp:
+        yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        fl = np.stack([3.0 * np.sin(yy / 17.0) + 0.7 * g.standard_normal((H, W)), 2.5 * np.cos(xx / 23.0) + 0.7 * g.standard_normal((H, W))])
+        fl = np.broadcast_to(fl[None], (B, 2, H, W)).astype(np.float32).copy()
+        fl[:, :, :3, :] += 4.0                               # the top rows point far outside
+    scale = 1.25
+    f2w = orc.backwarp_c(f2, fl * np.float32(scale)) if warp else f2
+    want = orc.correlation_c(f1, f2w, s)
+    want = np.where(want >= 0, want, 0.1 * want).astype(np.float32)
+    t1, t2, tf = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev), torch.from_numpy(fl).to(dev) if warp else None
+    got = _fused(t1, t2, tf, scale, s, 1, dev, True).cpu().numpy()
+    # the reference's back-warp goes through normalised coordinates ((x + u) / ((W - 1) / 2) - 1 and back, src/models.py:22-35): its
+    # sample positions carry a rounding of ~W * 2^-24 px, so the bound of the warp (2e-5 at the fixtures' <= 160 px) grows with the
+    # image; the library's two kernels, which both work in pixel units, must agree with each other far below that
+    other = _fused(t1, t2, tf, scale, s, 1, dev, False).cpu().numpy()          # the NCHW kernel of the Python surface
+    assert rel(got, other) < 3e-6, rel(got, other)
+    assert rel(got, want) < 3e-5 * max(1.0, max(H, W) / 256.0), (rel(got, want), rel(other, want))
+
+
+def test_warp_corr_timed_hook_and_batch_invariance(dev):
+    """pivlfn_warp_corr_nhwc_timed returns a plausible per-dispatch time and leaves the same output as a plain launch; one image of
+    a batch equals that image alone bit for bit although the batch runs the sliding-window kernel and the single image does not."""
+    import ctypes
+    lib = _lib.load()
+    B, C, n, s = 4, 64, 128, 2
+    g = torch.Generator(device=dev).manual_seed(3)
+    f1 = torch.randn(B, n, n, C, device=dev, generator=g)
+    f2 = torch.randn(B, n, n, C, device=dev, generator=g)
+    fl = torch.zeros(B, n, n, 4, device=dev)
+    fl[..., :2] = torch.randn(B, n, n, 2, device=dev, generator=g)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = torch.empty(B, n // s, n // s, 56, device=dev)
+    _lib.check(lib.pivlfn_warp_corr_nhwc(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out.data_ptr(), B, C, n, n, s, 1, st), "wc")
+    out2 = torch.empty_like(out)
+    us = ctypes.c_double(-1.0)
+    _lib.check(lib.pivlfn_warp_corr_nhwc_timed(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out2.data_ptr(), B, C, n, n, s, 1, 5,
+                                               ctypes.byref(us), st), "wc timed")
+    assert torch.equal(out, out2) and 1.0 < us.value < 1000.0
+    assert lib.pivlfn_warp_corr_nhwc_timed(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out2.data_ptr(), B, C, n, n, s, 1, 0,
+                                           ctypes.byref(us), st) != 0
+    for k in range(B):
+        one = torch.empty(1, n // s, n // s, 56, device=dev)
+        _lib.check(lib.pivlfn_warp_corr_nhwc(f1[k:k + 1].data_ptr(), f2[k:k + 1].data_ptr(), fl[k:k + 1].data_ptr(), 1.25, one.data_ptr(),
+                                             1, C, n, n, s, 1, st), "wc one")
+        assert torch.equal(one[0], out[k])
 
 
 def test_resize_bilinear_matches_torch(dev):

@@ -53,10 +53,13 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES)
+FULL_OCCUPANCY = [c for c in CASES if c[2] * c[3] * c[4] >= 100000]
+
+
+@pytest.mark.parametrize("case", CASES + [c + (1,) for c in FULL_OCCUPANCY])      # the full-occupancy shapes under a second seed
 def test_wino_matches_float64_conv(case, dev):
-    co, ci, H, W, B = case
-    g = torch.Generator().manual_seed(co * 1000 + ci + H)
+    co, ci, H, W, B = case[:5]
+    g = torch.Generator().manual_seed(co * 1000 + ci + H + (7919 * case[5] if len(case) > 5 else 0))
     w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
     b = torch.randn(co, generator=g) * 0.1
     x = torch.randn(B, ci, H, W, generator=g)

@@ -19,22 +19,23 @@ tiles = (n // s // 8) ** 2 * batch
 
 
 def counters(tag):
-    """Counter values of the level's launches: both kernels run one tile per workgroup, so the launch of a level is the one whose
-    workgroup count is that level's tile count (level 3 at batch 1: the latency kernel "v4", 256; level 2: 1024; level 1: 4096;
-    bench.py's batch-8 level-3 measurement: 2048)."""
+    """Counter values of the level's launches.  Round 4: the kernels are persistent (the grid no longer tells the level), so
+    the launches are picked by position: a lean bench run consists of forwards only and a forward launches warp+correlation for
+    levels 6, 5, 4, 3, 2, 1 in that order (dispatch k of the process -> level 6 - k % 6); the batch-8 figures come from a
+    process that launches nothing else (tools/wc_standalone.py), its first two launches dropped as warm-up."""
     rows = []
-    for path in glob.glob(os.path.join(out_dir, tag, "**", "*counter_collection.csv"), recursive=True):
+    sub = ("b8_" if batch == 8 else "net_") + tag
+    for path in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
         rows += [r for r in csv.DictReader(open(path)) if "warp_corr" in r["Kernel_Name"]]
-    def nwg(r):
-        wg = int(r["Workgroup_Size"]) if "Workgroup_Size" in r else int(r["Workgroup_Size_X"])
-        grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
-        return grid // wg
     by_disp = {}
     for r in rows:
         by_disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
     ids = sorted(by_disp)
-    tag_ = "v4" if tiles <= 512 else "v3"
-    pick = [d for d in ids if nwg(by_disp[d][0]) == tiles and tag_ in by_disp[d][0]["Kernel_Name"]]
+    if batch == 8:
+        pick = ids[2:]
+    else:
+        assert len(ids) % 6 == 0, f"{len(ids)} warp+correlation dispatches: not a whole number of forwards"
+        pick = [d for k, d in enumerate(ids) if 6 - k % 6 == level][1:]          # the first forward is the warm-up
     vals = {}
     for d in pick:
         for r in by_disp[d]:
@@ -63,5 +64,5 @@ print(json.dumps({
     "algorithmic_bytes_per_launch": alg,
     "TCC_HIT_sum": mean(res.get("TCC_HIT_sum", {})), "TCC_MISS_sum": mean(res.get("TCC_MISS_sum", {})),
     "kernel_source_sha256_16": h.hexdigest()[:16],
-    "passes": "three separate rocprofv3 --pmc runs of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0 --no-arithmetic` (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum), tools/pmc_l3.sh",
+    "passes": "three separate rocprofv3 --pmc runs (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0 --no-arithmetic --lean` (batch 1, launches picked by position in the forward) or of `tools/wc_standalone.py --level 3 --batch 8` (batch 8), tools/pmc_l3.sh",
 }, indent=1))
