@@ -146,7 +146,10 @@ size_t pivlfn_levels_floats(const pivlfn_net *net, int B, int H, int W);
  * timed on its own.  weight: host, OIHW [cout,cin,kh,kw]; bias: host [cout].
  * x: [B,H,W,x_stride] (first cin lanes used, x_stride % 4 == 0, lanes cin..roundup(cin,4) must be finite);
  * y: [B,Ho,Wo,y_stride], lanes cout..min(roundup(cout,4), y_stride) are written as exact zeros;
- * res (optional): same grid as y, added before the activation; leaky: LeakyReLU(0.1) on the result. */
+ * res (optional): same grid as y, added before the activation; leaky: LeakyReLU(0.1) on the result.
+ * Dispatch = the PIVLFN_PRECISION_F32 network's for the shape, except Winograd (own entry point below): the direct kernel
+ * everywhere, but a 7 x 1 layer (pad 3, 0; no residual, no activation) on an image of >= 256 x 256 pixels runs on the streaming
+ * matrix-core kernel pivlfn_forward uses for conv_dist_R.0 there -- not bit-comparable with the F32_DIRECT network's layer. */
 typedef struct pivlfn_conv pivlfn_conv;
 int pivlfn_conv_create(const float *weight, const float *bias, int cout, int cin, int kh, int kw, pivlfn_conv **out);
 int pivlfn_conv_destroy(pivlfn_conv *conv);

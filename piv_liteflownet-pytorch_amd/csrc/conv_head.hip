@@ -382,6 +382,8 @@ int launch_conv_col7(const float *x, int x_stride, const float *wf, const float 
 {
     PIV_REQUIRE(x && wf && bias && out && B > 0 && H > 0 && W > 0, "conv_col7: bad arguments");
     PIV_REQUIRE(x_stride % 4 == 0 && out_stride % 4 == 0 && cout_store % 4 == 0 && cout_store <= 64 && cout_store <= out_stride, "conv_col7: bad strides");
+    // the 49-channel path leaves channel 48's value in all four lane groups of block 3 and relies on only lane group 0 being stored
+    PIV_REQUIRE(!single48 || cout_store == 52, "conv_col7: the 49-channel layer stores 52 lanes (got %d)", cout_store);
     PIV_REQUIRE((long)H * W * x_stride * 4 < (1L << 31), "conv_col7: image exceeds 2 GiB");
     constexpr int TH = 16;
     hipLaunchKernelGGL((conv_col7_kernel<TH>), dim3(cdiv(W, 16) * cdiv(H, TH) * B), dim3(256), 0, st, x, x_stride, wf, bias, out, out_stride, cout_store, single48, B, H, W);

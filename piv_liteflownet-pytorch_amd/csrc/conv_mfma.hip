@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
     // the patch carries an out-of-range offset and the hardware's range check returns zeros -- no divergent branch around any load
     // (the predicated form cost an exec-mask save / branch / restore per load and turned the counted waits into vmcnt(0): on the
     // short K loops of NetC's stride-2 layers a quarter of a workgroup's time went into issuing them).
-    unsigned ppix[PMAX];       // index of the pixel inside its image, C2OOB = zero
+    // The descriptors start at the first image row of this workgroup's patch (64-bit scalar arithmetic): the 32-bit per-lane
+    // offsets only span the patch rows, so one image of a source may be of any size (round 3: < 2 GiB).
+    const int row0 = min(max(iy0, 0), p.H - 1);
+    unsigned ppix[PMAX];       // index of the pixel relative to (row0, 0) of its image, C2OOB = zero
     int plds[PMAX];            // LDS float offset
 #pragma unroll
     for (int i = 0; i < PMAX; ++i) {
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
         const int py = pix / PW, px = pix - py * PW;
         const int iy = iy0 + py, ix = ix0 + px;
         const bool ok = idx < npix2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        ppix[i] = ok ? (unsigned)(iy * p.W + ix) : C2OOB;
+        ppix[i] = ok ? (unsigned)((iy - row0) * p.W + ix) : C2OOB;      // relative to the descriptor's first row
         plds[i] = idx < npix2 ? pix * PIXP + q * 4 : -1;
     }
     const int q4 = (tid & 1) * 4;
@@ -230,8 +233,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
     while (seg + 1 < p.nseg && c0 >= p.seg[seg].cload) { c0 -= (p.seg[seg].cload + 7) / 8 * 8; ++seg; }
     int scl = p.seg[seg].cload, sst = p.seg[seg].stride;
     const size_t img_px = (size_t)p.H * p.W;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + (size_t)b * img_px * sst), 0,
-                                                                  (unsigned)(((img_px - 1) * sst + scl) * 4), 0x00020000);
+    const size_t px_left = (size_t)(p.H - row0) * p.W - 1;          // pixels from the base to the last one of the image
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + ((size_t)b * img_px + (size_t)row0 * p.W) * sst), 0,
+                                                                  (unsigned)min((px_left * sst + scl) * 4, (size_t)0x7fffffff), 0x00020000);
     unsigned pvo[PMAX];        // byte offset of the slot's 16 bytes inside the current source's image (pixel record + quad), C2OOB = zero
 #pragma unroll
     for (int i = 0; i < PMAX; ++i) pvo[i] = ppix[i] != C2OOB ? ppix[i] * (unsigned)(sst * 4) + (unsigned)q4 * 4u : C2OOB;
@@ -290,8 +294,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
                 ++seg;
                 c0 = 0;
                 scl = p.seg[seg].cload; sst = p.seg[seg].stride;
-                rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + (size_t)b * img_px * sst), 0,
-                                                       (unsigned)(((img_px - 1) * sst + scl) * 4), 0x00020000);
+                rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[seg].ptr + ((size_t)b * img_px + (size_t)row0 * p.W) * sst), 0,
+                                                       (unsigned)min((px_left * sst + scl) * 4, (size_t)0x7fffffff), 0x00020000);
 #pragma unroll
                 for (int i = 0; i < PMAX; ++i) pvo[i] = ppix[i] != C2OOB ? ppix[i] * (unsigned)(sst * 4) + (unsigned)q4 * 4u : C2OOB;
             }
@@ -623,8 +627,8 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
     p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only
     p.dbg = PIV_KNOB(7);
     const int taps = p.KH * p.KW;
-    for (int s = 0; s < p.nseg; ++s)      // 32-bit byte offsets inside one image of a source (buffer loads)
-        PIV_REQUIRE((size_t)p.H * p.W * p.seg[s].stride * 4 < 0x7fffffffull, "conv: one image of source %d (%d x %d x %d floats) exceeds the 2 GiB buffer-descriptor range", s, p.H, p.W, p.seg[s].stride);
+    for (int s = 0; s < p.nseg; ++s)      // 32-bit byte offsets inside the rows of one patch (the descriptors are rebased per workgroup)
+        PIV_REQUIRE((size_t)(15 * p.S + p.KH) * p.W * p.seg[s].stride * 4 < 0x7fffffffull, "conv: one patch (%d rows x %d x %d floats) of source %d exceeds the 2 GiB buffer-descriptor range", 15 * p.S + p.KH, p.W, p.seg[s].stride, s);
     // Split-K when one image has too few tiles for the chip and the K loop is long enough to be worth sharing.  Decided from
     // the per-image count of canonical (4 rows x 32 px x 32 channels) tiles only -- never from the batch size or from the tile
     // shape picked below (which does depend on it): a pair's flow must not depend on its batch mates, bit for bit.

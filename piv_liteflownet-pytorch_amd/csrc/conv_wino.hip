@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
     // through a per-image descriptor: a slot outside the image (the zero padding), past the patch, or past the source's channels
     // gets an out-of-range offset and returns zeros -- no divergent branch around a load, so the loop body stays straight-line
     // and the compiler's waits stay counted.  Slots past the patch land in a spare LDS record nobody reads.
+    // The descriptors start at the first image row of this workgroup's patch (64-bit scalar arithmetic) and the 32-bit per-lane
+    // offsets only span the patch rows: no limit on the size of one image (round 3 put the base at the image start and refused
+    // images of 2 GiB per source -- a 2048 x 2048 pair's 128-channel level-1 tensors).
+    const int row0 = max(y0 - 1, 0);
     unsigned ppix[PS];
     int plds[PS];
     const int q4 = (tid & 1) * 4;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
         const int py = pix / WPW, px = pix - py * WPW;
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool in = idx < NSLOT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        ppix[s] = in ? (unsigned)(iy * p.W + ix) : WOOB;
+        ppix[s] = in ? (unsigned)((iy - row0) * p.W + ix) : WOOB;       // relative to the descriptor's first row (below)
         plds[s] = (idx < NSLOT ? ((py >> 1) + (py & 1) * (PH / 2)) * WROWQ + ((px >> 1) + (px & 1) * 9) * WPIXQ : PH * WROWQ) + (tid & 1);
     }
     // plane row i = wave: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]
@@ -140,8 +144,9 @@ __global__ __launch_bounds__(256, (MB * NBW <= 2) ? 2 : 1) void conv_wino_kernel
         const int ss = s < p.nseg ? s : 0;
         sclv[s] = p.seg[ss].cload;
         sst4v[s] = p.seg[ss].stride * 4;
-        rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[ss].ptr + (size_t)b * img_px * p.seg[ss].stride), 0,
-                                                   (unsigned)(((img_px - 1) * p.seg[ss].stride + p.seg[ss].cload) * 4), 0x00020000);
+        const size_t left = ((size_t)(p.H - row0) * p.W - 1) * p.seg[ss].stride + p.seg[ss].cload;       // floats from the base to the end of the image
+        rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[ss].ptr + ((size_t)b * img_px + (size_t)row0 * p.W) * p.seg[ss].stride), 0,
+                                                   (unsigned)min(left * 4, (size_t)0x7fffffff), 0x00020000);
     }
     int seg = 0, c0 = 0, lchunk = 0;
     unsigned pvo[PS];             // byte offset of the slot's pixel record (+ its quad) inside the current source, WOOB = none
@@ -470,8 +475,8 @@ int launch_conv_w(const ConvParamsW &p_in, hipStream_t st)
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0 && p.out_stride % 4 == 0,
                 "conv_wino: cout_pad=%d cout_store=%d out_stride=%d", p.cout_pad, p.cout_store, p.out_stride);
     PIV_REQUIRE(p.B > 0 && p.H > 0 && p.W > 0 && (long)p.B * p.H * p.W < (1L << 31), "conv_wino: bad shape");
-    for (int s = 0; s < p.nseg; ++s)      // 32-bit byte offsets inside one image of a source
-        PIV_REQUIRE((long)p.H * p.W * p.seg[s].stride * 4 < (1L << 31), "conv_wino: image of source %d exceeds 2 GiB", s);
+    for (int s = 0; s < p.nseg; ++s)      // 32-bit byte offsets inside the rows of one patch (descriptors are rebased per workgroup)
+        PIV_REQUIRE((long)20 * p.W * p.seg[s].stride * 4 < (1L << 31), "conv_wino: 20 rows of source %d exceed 2 GiB", s);
     int nchunk = 0;
     for (int s = 0; s < p.nseg; ++s) {
         PIV_REQUIRE(p.seg[s].cload % 4 == 0 && p.seg[s].stride % 4 == 0 && p.seg[s].ptr, "conv_wino: segment %d misaligned", s);

@@ -1028,11 +1028,12 @@ __device__ __forceinline__ void k6_reduce(const K6Acc &A, int lane, float (&r2)[
 }
 
 // Tools build: lane 0 of one wave per role (0 consumer wave 0, 1 helper, 2 producer wave 8, 3 producer wave 15) stamps s_memtime
-// at three points of every step (after the barrier, after its first wait, at the end of its work): 96 stamps per role and workgroup.
+// at three points of every step (after the barrier, after its first wait, at the end of its work): 96 stamps per role and workgroup;
+// enabled by dbg bit 32 (the stamp buffer is shared with v7's records: tools/wc_probe.py).
 #ifdef PIVLFN_STAMPS
 #define K6_STAMP(role, idx)                                                                        \
     do {                                                                                           \
-        if (p.stamps && lane == 0 && (unsigned)(idx) < 96u) p.stamps[((size_t)blockIdx.x * 4 + (role)) * 96 + (idx)] = __builtin_amdgcn_s_memtime(); \
+        if (p.stamps && (p.dbg & 32) && lane == 0 && (unsigned)(idx) < 96u) p.stamps[((size_t)blockIdx.x * 4 + (role)) * 96 + (idx)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define K6_STAMP(role, idx) do { } while (0)
@@ -1387,6 +1388,9 @@ static int launch_wc6(WcParams p, hipStream_t st)
 //     instructions and 56 LDS reads per 64 channels and lane where v4 spent 4700-5000 cycles on LDS-bound reads (14 waves with two
 //     rows per lane need 40 % more LDS bytes and were LDS-bound at twice the time);
 //   * output transpose channel-major with an odd pitch: conflict-free stores (v4 / v6: 8-way conflicts on 7 stores per lane).
+// Measured and dropped: gathers in plane order (a thread = one position and one 16-byte quad of each 16-channel plane, so that the
+// dot products of a plane run under the arrival of the next): 64-byte pieces instead of whole 256-byte pixels per tap -- twice
+// the lines per load instruction -- took the launch from 7.5 to 17.3 us.
 // Summation order = v6's (four quad-lane chains over 16-channel planes ascending, (S_0 + S_1) + (S_2 + S_3), blend_taps for
 // every position): a level's bits do not depend on which of the two kernels its launch size selects.
 constexpr int K7_PLANE = NPOS * 64 + 64;                   // one 16-channel plane of the warped tile

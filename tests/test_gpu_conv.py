@@ -118,3 +118,32 @@ def test_flow_head_kernel_matches_torch(k, dev):
         assert torch.all(out[..., 2:] == 0)
         got = out[..., :2].permute(0, 3, 1, 2).double()
         assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("kernel", ["direct", "wino"])
+def test_images_of_2_gib_and_more_per_source(kernel, dev):
+    """One image of a source may be of any size (a 2048 x 2048 pair's 128-channel level-1 tensors are exactly
+    2^31 bytes and round 3's kernels refused them): the per-workgroup buffer descriptors start at the tile's first patch row, so the
+    32-bit per-lane offsets only span those rows.  Forced here with a wide pixel stride: 264 x 260 pixels x 8192 floats = 2.25 GB
+    for 8 real channels; the last rows lie beyond 2^31 bytes from the image start."""
+    H, W, ci, co, xs = 264, 260, 8, 32, 8192
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    b = torch.randn(co, generator=g) * 0.1
+    x = torch.randn(1, ci, H, W, generator=g)
+    conv = Conv(w, b)
+    xd = torch.zeros(1, H, W, xs, device=dev)
+    xd[..., :ci] = x.permute(0, 2, 3, 1).to(dev)
+    assert xd.numel() * 4 >= 2 ** 31
+    ys = co
+    y = torch.full((1, H, W, ys), float("nan"), device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    lib = _lib.load()
+    if kernel == "direct":
+        _lib.check(lib.pivlfn_conv2d_nhwc(conv.h, xd.data_ptr(), xs, y.data_ptr(), ys, None, ys, 1, H, W, 1, 1, 1, 1, st), "conv2d")
+    else:
+        _lib.check(lib.pivlfn_conv2d_nhwc_wino(conv.h, xd.data_ptr(), xs, y.data_ptr(), ys, 1, H, W, 1, st), "conv2d_wino")
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1)
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    del xd
+    assert (got - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _toolslib  # noqa: E402
 from pivlfn import _lib  # noqa: E402
 
-PH = ["entry->taps", "barrier1", "issue", "arrive+commit", "barrier2", "dots", "barrier3", "transpose+bar4", "store issue"]
+PH = ["entry->taps", "(v4: barrier1)", "issue", "arrive+commit", "barrier2", "dots", "reduce+transpose (v4: barrier3)", "barrier (v4: transpose+bar4)", "store issue"]
 
 
 def report(tag, stamps, nwg, brief=False):
