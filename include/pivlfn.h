@@ -35,7 +35,7 @@ typedef struct {
 } pivlfn_tensor;
 
 const char *pivlfn_last_error(void);
-/* ABI version.  2 (round 4): + pivlfn_warp_corr_nhwc_timed; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
+/* ABI version.  2 (round 4): + pivlfn_warp_corr_nhwc_timed, pivlfn_conv2d_nhwc_wino4; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
  * (added in round 3 without a bump).  No entry point of version 1 changed its signature or meaning. */
 int         pivlfn_abi_version(void);
 
@@ -171,6 +171,9 @@ int pivlfn_conv2d_nhwc_split(const pivlfn_conv *conv, const float *x, int x_stri
  * fp32 y, output grid = input grid. */
 int pivlfn_conv2d_nhwc_wino(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                             int B, int H, int W, int leaky, void *stream);
+/* The same layer on the Winograd F(4x4, 3x3) kernel PIVLFN_PRECISION_F32 uses from 256 x 256 output pixels per image up. */
+int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                             int B, int H, int W, int leaky, void *stream);
 
 /* The 32 -> 2 channel k x k flow head (conv_M.6 / conv_S.6) on its dedicated kernel: x [B,H,W,32], res4/out4 [B,H,W,4]. */
 int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W,

@@ -56,7 +56,7 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
                    int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, int terms, hipStream_t st);
 int conv_head_forward(const pivlfn_conv *c, const float *x, const float *res4, float *out4, int B, int H, int W, hipStream_t st);
 int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, int B, int H, int W, int leaky,
-                   hipStream_t st);
+                   hipStream_t st, int tile);
 
 }  // namespace pivlfn
 
@@ -165,7 +165,13 @@ int pivlfn_conv2d_nhwc_split(const pivlfn_conv *conv, const float *x, int x_stri
 int pivlfn_conv2d_nhwc_wino(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                             int B, int H, int W, int leaky, void *stream)
 {
-    return conv_forward_w(conv, x, x_stride, y, y_stride, B, H, W, leaky, (hipStream_t)stream);
+    return conv_forward_w(conv, x, x_stride, y, y_stride, B, H, W, leaky, (hipStream_t)stream, 2);
+}
+
+int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                             int B, int H, int W, int leaky, void *stream)
+{
+    return conv_forward_w(conv, x, x_stride, y, y_stride, B, H, W, leaky, (hipStream_t)stream, 4);
 }
 
 int pivlfn_set_precision(pivlfn_net *net, int precision) { return net_set_precision(net, precision); }

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--layers", default="")
     ap.add_argument("--ab", default="", help="path of a second build of libpivlfn.so: its Winograd kernel is timed beside the current one (interleaved rounds)")
+    ap.add_argument("--w4", action="store_true", help="--masks are ablation masks of the F(4x4) kernel (1 no MFMAs, 2 no transform, 4 no weight loads, 8 no patch loads, 16 no epilogue)")
     ap.add_argument("--masks", default="", help="tools build only: per-variant masks of the Winograd kernel: (m >> 8) & 255 = forced tile shape (11, 21, 22, 14), 65536 = one workgroup per CU")
     ap.add_argument("--stamps", action="store_true", help="tools build only: phase times of wave 0 of every workgroup (s_memtime ticks) for the two-block shape, at two and at one workgroup per CU")
     a = ap.parse_args()
@@ -108,7 +109,11 @@ def main():
 
             def wino():
                 _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y["wino"].data_ptr(), co, a.batch, n, n, 1, st), "wino")
-            fns = {"direct": direct, "wino": wino}
+            y["wino4"] = torch.empty(a.batch, n, n, co, device=dev)
+
+            def wino4():
+                _lib.check(lib.pivlfn_conv2d_nhwc_wino4(h, x.data_ptr(), xs, y["wino4"].data_ptr(), co, a.batch, n, n, 1, st), "wino4")
+            fns = {"direct": direct, "wino": wino, "wino4": wino4}
             if lib_b is not None:
                 hb = ctypes.c_void_p()
                 _lib.check(lib_b.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(hb)), "create b")
@@ -121,6 +126,11 @@ def main():
                 fns = {}
                 for m in [int(v) for v in a.masks.split(",")]:
                     def wm(m=m):
+                        if a.w4:
+                            lib.pivlfn_tune(7, m)
+                            wino4()
+                            lib.pivlfn_tune(7, 0)
+                            return
                         lib.pivlfn_tune(13, m & 255)
                         lib.pivlfn_tune(14, (m >> 8) & 255)
                         lib.pivlfn_tune(1, (m >> 16) << 20)
@@ -175,6 +185,11 @@ def main():
             print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: direct min {td:8.1f} med {md:8.1f} us ({flop / td / 1e6:6.1f} TF)   "
                   f"wino min {tw:8.1f} med {mw:8.1f} us ({flop / tw / 1e6:6.1f} TF-equiv, {flop / 2.25 / tw / 1e6:6.1f} TF executed)   "
                   f"x{td / tw:4.2f}   rel diff {d:.1e}", flush=True)
+            if "wino4" in times:
+                d4 = (y["wino4"] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
+                t4, m4 = min(times["wino4"]), sorted(times["wino4"])[len(times["wino4"]) // 2]
+                print(f"        F(4x4): min {t4:8.1f} med {m4:8.1f} us ({flop / t4 / 1e6:6.1f} TF-equiv, {flop / 4.0 / t4 / 1e6:6.1f} TF executed)   "
+                      f"x{td / t4:4.2f} vs direct, x{tw / t4:4.2f} vs F(2x2)   rel diff {d4:.1e}", flush=True)
             lib.pivlfn_conv_destroy(h)
 
 
