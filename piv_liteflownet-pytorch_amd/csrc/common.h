@@ -176,7 +176,6 @@ struct ConvParamsW {
 };
 int launch_conv_w(const ConvParamsW &p, hipStream_t st);
 int launch_conv_w4(const ConvParamsW &p, hipStream_t st);      // F(4x4, 3x3): wpk = [nchunk][cout_pad/32][6][6][64][4] (pack_conv_w4)
-constexpr long W4_MIN_PIXELS = 256L * 256L;                    // output pixels per image from which pivlfn_forward uses F(4x4, 3x3)
 bool conv_wino_supports(int KH, int KW, int S, int padY, int padX);
 // 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device
 // (7 x 1) convolution from 32 channels to up to 64 on v_mfma_f32_16x16x4_f32, operands from global memory (conv_head.hip)

@@ -36,11 +36,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int W4_PW = 34, W4_PH = 18;           // patch: 32 + 2 columns, 16 + 2 rows
-constexpr int W4_PIXQ = 3;                      // quads per staged pixel (8 channels + 4 floats of padding)
-constexpr int W4_ROWQ = 104;                    // quads per patch row: 34 x 3 = 102, padded to 8 mod 16
-constexpr int W4_NSLOT = W4_PH * W4_PW * 2;     // 16-byte slots of one chunk's patch
-constexpr int W4_PS = (W4_NSLOT + 767) / 768;   // slots per thread
-constexpr int W4_PBUF = W4_PH * W4_ROWQ + 4;    // quads per patch buffer (+ a spare record for slots past the patch)
+// The patch is staged 16 channels (two 8-channel K chunks) at a time: 64 bytes per pixel and load instead of 32 -- with 8-channel
+// staging every chunk touched all 612 128-byte lines of the patch again, the CU's L1 cannot hold them (78 KB), and the L2 -> L1 path
+// (34 B/clk wanted) was what the kernel waited for: -20 % with the patch loads removed (tools/w4_ablate.sh).
+constexpr int W4_PIXQ = 5;                      // quads per staged pixel: 16 channels + 4 floats of padding (odd)
+constexpr int W4_ROWQ = 184;                    // quads per patch row: 34 x 5 = 170, padded to 8 mod 16
+constexpr int W4_NSLOT = W4_PH * W4_PW * 4;     // 16-byte slots of one 16-channel unit: 2448
+constexpr int W4_PBUF = W4_PH * W4_ROWQ + 8;    // quads per patch buffer (+ a spare record for slots past the patch): 53 KB
 constexpr unsigned W4OOB = 0x80000000u;
 
 // position of patch row y / column x in the de-interleaved image: rows y = 0, 4, 8, .. first, then 1, 5, .., ...
@@ -58,7 +60,7 @@ template <int HH>
 struct W4Xform {
     f32x4 V[3], u, v;       // u, v: column values / partial forms carried between folds
     f32x4 e[4];             // reads in flight
-    __device__ __forceinline__ void issue(int l, const f32x4 *smem4, int bo, const int (&vrow)[4])
+    __device__ __forceinline__ void issue(int l, const f32x4 *smem4, int bo, const int (&vrow)[4])      // bo: buffer + 2 * sub-chunk
     {
         const int co = w4_cpos(HH + l) * W4_PIXQ;
 #pragma unroll
@@ -109,22 +111,23 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(const ConvParamsW p)
     const int n = lane & 31, g = lane >> 5;
     const int ty = n >> 3, tx = n & 7;
 
-    // staging slots: slot s covers (pixel, quad) = (idx >> 1, idx & 1), idx = tid + 768 s; buffer loads through per-image descriptors
-    // that start at the patch's first image row: a slot outside the image (the zero padding), past the patch or past the source's
-    // channels gets an out-of-range offset and reads zeros; slots past the patch land in a spare LDS record
+    // staging slots of a 16-channel unit: slot s covers (pixel, quad) = (idx >> 2, idx & 3), idx = tid + 768 s, s = 0..3 (slots 0, 1 =
+    // half A, 2, 3 = half B of the unit); buffer loads through per-image descriptors that start at the patch's first image row: a slot
+    // outside the image (the zero padding), past the patch or past the source's channels gets an out-of-range offset and reads zeros;
+    // slots past the patch land in a spare LDS record
     const int row0 = max(y0 - 1, 0);
-    unsigned ppix[W4_PS];
-    int plds[W4_PS];
-    const int q4 = (tid & 1) * 4;
+    unsigned ppix[4];
+    int plds[4];
+    const int q4 = (tid & 3) * 4;
 #pragma unroll
-    for (int s = 0; s < W4_PS; ++s) {
+    for (int s = 0; s < 4; ++s) {
         const int idx = tid + 768 * s;
-        const int pix = idx >> 1;
+        const int pix = idx >> 2;
         const int py = pix / W4_PW, px = pix - py * W4_PW;
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool in = idx < W4_NSLOT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         ppix[s] = in ? (unsigned)((iy - row0) * p.W + ix) : W4OOB;
-        plds[s] = (idx < W4_NSLOT ? w4_rpos(py) * W4_ROWQ + w4_cpos(px) * W4_PIXQ : W4_PH * W4_ROWQ) + (tid & 1);
+        plds[s] = (idx < W4_NSLOT ? w4_rpos(py) * W4_ROWQ + w4_cpos(px) * W4_PIXQ : W4_PH * W4_ROWQ) + (tid & 3);
     }
 
     // the wave's row form: t = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3]
@@ -140,10 +143,6 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(const ConvParamsW p)
     }
 
     f32x16 acc[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
     // weights of (chunk, nb0, plane (pi, 3 ph + k)): 64 lanes x 4 floats, contiguous
     const float *wbase = p.wpk + (((size_t)nb0 * 36 + pi * 6 + 3 * ph) * 64 + lane) * 4;
@@ -161,134 +160,136 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(const ConvParamsW p)
         rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[ss].ptr + ((size_t)b * img_px + (size_t)row0 * p.W) * p.seg[ss].stride), 0,
                                                    (unsigned)min(left * 4, (size_t)0x7fffffff), 0x00020000);
     }
-    int seg = 0, cc0 = 0, lchunk = 0;
-    unsigned pvo[W4_PS];
-#pragma unroll
-    for (int s = 0; s < W4_PS; ++s) pvo[s] = ppix[s] != W4OOB ? ppix[s] * (unsigned)sst4v[0] + (unsigned)q4 * 4u : W4OOB;
-    f32x4 pr[W4_PS], wA[3];
-#if W4_ABL_CT
-    for (int s = 0; s < W4_PS; ++s) pr[s] = f32x4{1.f, 2.f, 3.f, 4.f};
-    for (int k = 0; k < 3; ++k) wA[k] = f32x4{1.f, 2.f, 3.f, 4.f};
-#endif
-
-// ablation for timing only (results wrong): compile-time mask W4_ABL_CT (tools/w4_ablate.sh builds one library per mask; a run-time
-// mask puts branches around the loads and MFMAs and times a different kernel)
+    // staging state: the next half to load is half `hq & 1` of the 16-channel unit at (seg, cc0); units cover every source in steps
+    // of 16 channels (the last unit of a source may hold fewer: its missing quads read zeros and meet zero weights)
 #ifndef W4_ABL_CT
 #define W4_ABL_CT 0
 #endif
 #define W4_ABL(BIT) ((W4_ABL_CT & (BIT)) != 0)
-// patch of chunk `lchunk` -> pr, then advance to the next chunk; past the end the last chunk is fetched again (into a buffer nobody
-// reads any more): no branch around a load
-#define W4_LOADP()                                                                                \
+    int seg = 0, cc0 = 0, ubuf = 0;      // ubuf: buffer of the unit whose halves are being loaded
+    f32x4 pr[2], wA[3];
+#if W4_ABL_CT
+    for (int s = 0; s < 2; ++s) pr[s] = f32x4{1.f, 2.f, 3.f, 4.f};
+    for (int k = 0; k < 3; ++k) wA[k] = f32x4{1.f, 2.f, 3.f, 4.f};
+#endif
+
+// half HB (compile-time: 0 = slots 0, 1; 1 = slots 2, 3) of the unit at (seg, cc0) -> pr (two slots per thread); after half 1 the
+// unit advances; past the last unit the loads are out of range.  (With the half as a run-time index the slot arrays went to scratch.)
+#define W4_LOADH(HB)                                                                              \
     do {                                                                                          \
         const int scl_ = seg == 0 ? sclv[0] : (seg == 1 ? sclv[1] : sclv[2]);                     \
+        const int sst4_ = seg == 0 ? sst4v[0] : (seg == 1 ? sst4v[1] : sst4v[2]);                 \
         const __amdgpu_buffer_rsrc_t rs_ = seg == 0 ? rsv[0] : (seg == 1 ? rsv[1] : rsv[2]);      \
-        const bool qok_ = cc0 + q4 < scl_;                                                        \
-        _Pragma("unroll") for (int s = 0; s < W4_PS; ++s)                                         \
-            if (!W4_ABL(8)) pr[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? pvo[s] : W4OOB), cc0 * 4, 0)); \
-        if (lchunk + 1 < p.nchunk) {                                                              \
-            ++lchunk;                                                                             \
-            cc0 += 8;                                                                             \
-            if (cc0 >= scl_) {                                                                    \
-                ++seg;                                                                            \
-                cc0 = 0;                                                                          \
-                const int sst4_ = seg == 1 ? sst4v[1] : sst4v[2];                                 \
-                _Pragma("unroll") for (int s = 0; s < W4_PS; ++s)                                 \
-                    pvo[s] = ppix[s] != W4OOB ? ppix[s] * (unsigned)sst4_ + (unsigned)q4 * 4u : W4OOB; \
-            }                                                                                     \
+        const bool qok_ = (seg < p.nseg) & (cc0 + q4 < scl_);                                     \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                           \
+            const unsigned px_ = ppix[2 * (HB) + s];                                              \
+            const unsigned off_ = (qok_ & (px_ != W4OOB)) ? px_ * (unsigned)sst4_ + (unsigned)q4 * 4u : W4OOB; \
+            if (!W4_ABL(8)) pr[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)off_, cc0 * 4, 0)); \
+        }                                                                                         \
+        if (HB) {                                                                                 \
+            ubuf ^= 1;                 /* the next unit goes to the other buffer */                \
+            cc0 += 16;                                                                            \
+            if (cc0 >= scl_) { ++seg; cc0 = 0; }                                                  \
         }                                                                                         \
     } while (0)
-#define W4_LOADW(WN, CH)                                                                          \
+// commit half HB into buffer UB
+#define W4_COMMITH(HB, UB)                                                                        \
     do {                                                                                          \
-        const float *w_ = wbase + (size_t)(CH)*wchunk;                                            \
-        _Pragma("unroll") for (int k = 0; k < 3; ++k) WN[k] = *reinterpret_cast<const f32x4 *>(w_ + k * 256); \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) smem4[(UB) * W4_PBUF + plds[2 * (HB) + s]] = pr[s]; \
     } while (0)
-#define W4_COMMIT(BOFF)                                                                           \
-    do {                                                                                          \
-        _Pragma("unroll") for (int s = 0; s < W4_PS; ++s) smem4[(BOFF) + plds[s]] = pr[s];        \
-    } while (0)
-// One chunk: the patch of chunk CH + 2 goes out first (global -> registers); the twelve MFMAs of chunk CH go out in five groups, and
-// chunk CH + 1's transform (its patch was committed a step ago) sits between them column by column -- a column's four LDS reads
-// are issued in front of a group and used behind it, so neither LDS latency nor the barrier's lockstep of the twelve waves leaves
-// the matrix pipe waiting for a transform; the MFMAs go plane by plane, and a plane's weight register receives the next chunk's
-// fragment right behind its fourth MFMA (issued at the end of the step, the 36 KB of fragments of the twelve waves and the patch
-// loads queue up in the CU's load path and the next step's first MFMA waits ~2000 cycles for them: measured, 40 % matrix-pipe use); the patch of chunk CH + 2 is committed into the buffer chunk CH came from; barrier.
+#define W4_LW1(K, CH) if (!W4_ABL(4)) wA[K] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)((CH) + 1 < p.nchunk ? (CH) + 1 : (CH)) * wchunk + (K) * 256)
 #define W4_MF(XC, J, K) if (!W4_ABL(1)) acc[K] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[K][J], XC.V[K][J], acc[K], 0, 0, 0)      /* k-th element pair J of plane K */
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
-#define W4_LW1(K, CH) if (!W4_ABL(4)) wA[K] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)((CH) + 1 < p.nchunk ? (CH) + 1 : (CH)) * wchunk + (K) * 256)
-#define W4_STEP(XC, XN, CH, BO)                                                                   \
+// Step k = K chunk k = sub-chunk k & 1 of unit k >> 1 (every source is packed in whole units: an odd chunk count is padded with a
+// zero chunk).  Half k + 3 of the patch stream goes out first (global -> registers); the twelve MFMAs of chunk k go plane by plane,
+// and a plane's weight register receives the next chunk's fragment right behind its fourth MFMA; chunk k + 1's transform (reads of
+// unit (k + 1) >> 1, complete since the end of step k - 1) sits between the MFMAs column by column -- a column's four LDS reads are
+// issued in front of a group and used behind it; the half is committed (into the buffer unit (k - 1) >> 1 has left); barrier.
+#define W4_STEP(XC, XN, CH, HB)                                                                   \
     do {                                                                                          \
-        W4_LOADP();                                                                               \
-        if (!W4_ABL(2)) XN.issue(0, smem4, W4_PBUF - (BO), vrow);                                                 \
+        const int bn_ = ((((CH) + 1) >> 1) & 1) * W4_PBUF + 2 * (((CH) + 1) & 1);                  \
+        const int ub_ = ubuf;          /* buffer of the half loaded now (W4_LOADH flips ubuf behind half 1) */ \
+        W4_LOADH(HB);                                                                             \
+        if (!W4_ABL(2)) XN.issue(0, smem4, bn_, vrow);                                            \
         W4_SB();                                                                                  \
         W4_MF(XC, 0, 0); W4_MF(XC, 1, 0); W4_MF(XC, 2, 0);                                        \
         W4_SB();                                                                                  \
-        if (!W4_ABL(2)) XN.fold(0, c0, c1, c2); if (!W4_ABL(2)) XN.issue(2, smem4, W4_PBUF - (BO), vrow);                         \
+        if (!W4_ABL(2)) { XN.fold(0, c0, c1, c2); XN.issue(2, smem4, bn_, vrow); }                \
         W4_SB();                                                                                  \
         W4_MF(XC, 3, 0);                                                                          \
-        W4_LW1(0, CH);             /* plane 0 is done with its fragment: the next chunk's goes out a whole step ahead of its use */ \
+        W4_LW1(0, CH);                                                                            \
         W4_MF(XC, 0, 1); W4_MF(XC, 1, 1);                                                         \
         W4_SB();                                                                                  \
-        if (!W4_ABL(2)) XN.fold(2, c0, c1, c2); if (!W4_ABL(2)) XN.issue(1, smem4, W4_PBUF - (BO), vrow);                         \
+        if (!W4_ABL(2)) { XN.fold(2, c0, c1, c2); XN.issue(1, smem4, bn_, vrow); }                \
         W4_SB();                                                                                  \
         W4_MF(XC, 2, 1); W4_MF(XC, 3, 1);                                                         \
         W4_LW1(1, CH);                                                                            \
         W4_SB();                                                                                  \
-        if (!W4_ABL(2)) XN.fold(1, c0, c1, c2); if (!W4_ABL(2)) XN.issue(3, smem4, W4_PBUF - (BO), vrow);                         \
+        if (!W4_ABL(2)) { XN.fold(1, c0, c1, c2); XN.issue(3, smem4, bn_, vrow); }                \
         W4_SB();                                                                                  \
         W4_MF(XC, 0, 2); W4_MF(XC, 1, 2);                                                         \
         W4_SB();                                                                                  \
-        if (!W4_ABL(2)) XN.fold(3, c0, c1, c2); if (!W4_ABL(2)) XN.issue(4, smem4, W4_PBUF - (BO), vrow);                         \
+        if (!W4_ABL(2)) { XN.fold(3, c0, c1, c2); XN.issue(4, smem4, bn_, vrow); }                \
         W4_SB();                                                                                  \
         W4_MF(XC, 2, 2); W4_MF(XC, 3, 2);                                                         \
         W4_LW1(2, CH);                                                                            \
         W4_SB();                                                                                  \
-        if (!W4_ABL(2)) XN.fold(4, c0, c1, c2);                                                                   \
-        W4_COMMIT(BO);                                                                            \
-        __syncthreads();                                                                          \
+        if (!W4_ABL(2)) XN.fold(4, c0, c1, c2);                                                   \
+        if (!W4_ABL(64)) W4_COMMITH(HB, ub_);                                                     \
+        if (!W4_ABL(32)) __syncthreads();                                                         \
     } while (0)
 
     auto run = [&](auto hh) {
         constexpr int HH = decltype(hh)::value;
         W4Xform<HH> xa, xb;
-        W4_LOADW(wA, 0);
-        W4_LOADP();
-        W4_COMMIT(0);
-        W4_LOADP();
-        W4_COMMIT(W4_PBUF);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wA[k] = *reinterpret_cast<const f32x4 *>(wbase + k * 256);
+        // prologue: halves 0, 1, 2 (unit 0, half A of unit 1) in flight together -- one memory round trip, not three (with one
+        // workgroup per CU nothing else runs under it) -- then the transform of chunk 0
+        {
+            f32x4 p0[2], p1[2];
+            W4_LOADH(0); p0[0] = pr[0]; p0[1] = pr[1];
+            W4_LOADH(1); p1[0] = pr[0]; p1[1] = pr[1];
+            W4_LOADH(0);
+            W4_COMMITH(0, 1);
+            pr[0] = p0[0]; pr[1] = p0[1]; W4_COMMITH(0, 0);
+            pr[0] = p1[0]; pr[1] = p1[1]; W4_COMMITH(1, 0);
+        }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
         {
             constexpr int order[5] = {0, 2, 1, 3, 4};
 #pragma unroll
             for (int k = 0; k < 5; ++k) { xa.issue(order[k], smem4, 0, vrow); xa.fold(order[k], c0, c1, c2); }
         }
-        __syncthreads();            // every wave has read chunk 0's patch before the first step commits chunk 2 over it
         int chunk = 0;
         for (; chunk + 1 < p.nchunk; chunk += 2) {
-            W4_STEP(xa, xb, chunk, 0);
-            W4_STEP(xb, xa, chunk + 1, W4_PBUF);
+            W4_STEP(xa, xb, chunk, 1);              // even step k: half (k + 3) & 1 = 1 of unit (k + 3) >> 1
+            W4_STEP(xb, xa, chunk + 1, 0);
         }
-        if (chunk < p.nchunk) W4_STEP(xa, xb, chunk, 0);
     };
     if (ph == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
 #undef W4_MF
 #undef W4_SB
 #undef W4_LW1
-#undef W4_LOADP
-#undef W4_LOADW
-#undef W4_COMMIT
+#undef W4_LOADH
+#undef W4_COMMITH
 #undef W4_STEP
 
     // ---- output transform.  acc[k][4 rg + e] = M[(pi, 3 ph + k)][cout 32 nb0 + 8 rg + 4 g + e][tile n]
     // column part in registers: R[q] = sum_k A^T[q][3 ph + k] M[k]; row part across the plane rows through LDS:
     // Y[p][q] = sum_i A^T[p][i] (R_(i,0)[q] + R_(i,1)[q])
-    if (W4_ABL(16)) return;
-    f32x4 *xch = smem4;                 // [wave 12][q 4][lane 64] quads = 48 KB (the patch buffers are idle by now)
+    // two exchange areas [wave 12][q 4][lane 64] quads = 48 KB each (the patch buffers are idle by now): channel group rg writes area
+    // rg & 1, a barrier, then eight waves read it while all twelve already write group rg + 1 into the other area -- one barrier per
+    // channel group (an area is rewritten two barriers after it was read)
     const int oq = wave & 3, op = wave >> 2;          // waves 0..7: output column q = oq, output rows 2 op, 2 op + 1 of every tile
     const int cb = nb0 * 32 + 4 * g;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
+    auto put = [&](int rg) {
+        f32x4 *xch = smem4 + (rg & 1) * (12 * 4 * 64);
         f32x4 m[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -306,34 +307,43 @@ __global__ __launch_bounds__(768) void conv_wino4_kernel(const ConvParamsW p)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) xch[(wave * 4 + q) * 64 + lane] = R[q];
-        __syncthreads();
-        if (wave < 8) {
-            f32x4 S[6];
+    };
+    auto get = [&](int rg) {
+        if (wave >= 8) return;
+        const f32x4 *xch = smem4 + (rg & 1) * (12 * 4 * 64);
+        f32x4 S[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) S[i] = xch[((2 * i) * 4 + oq) * 64 + lane] + xch[((2 * i + 1) * 4 + oq) * 64 + lane];
-            const f32x4 s12 = S[1] + S[2], d12 = S[1] - S[2], s34 = S[3] + S[4], d34 = S[3] - S[4];
-            f32x4 ya, yb;
-            if (op == 0) {
-                ya = (S[0] + s12) + s34;                    // row 0: 1 1 1 1 1 0
-                yb = w4_fma(2.f, d34, d12);                 // row 1: 0 1 -1 2 -2 0
-            } else {
-                ya = w4_fma(4.f, s34, s12);                 // row 2: 0 1 1 4 4 0
-                yb = w4_fma(8.f, d34, d12) + S[5];          // row 3: 0 1 -1 8 -8 1
-            }
-            const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + cb + 8 * rg);
-            ya += bias4; yb += bias4;
-            if (p.lrelu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ya[e] = lrelu01(ya[e]); yb[e] = lrelu01(yb[e]); }
-            }
-            const int ox = x0 + 4 * tx + oq, oy = y0 + 4 * ty + 2 * op;
-            if (ox < p.W && cb + 8 * rg < p.cout_store) {
-                if (oy < p.H) *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.H + oy) * p.W + ox) * p.out_stride + cb + 8 * rg) = ya;
-                if (oy + 1 < p.H) *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.H + oy + 1) * p.W + ox) * p.out_stride + cb + 8 * rg) = yb;
-            }
+        for (int i = 0; i < 6; ++i) S[i] = xch[((2 * i) * 4 + oq) * 64 + lane] + xch[((2 * i + 1) * 4 + oq) * 64 + lane];
+        const f32x4 s12 = S[1] + S[2], d12 = S[1] - S[2], s34 = S[3] + S[4], d34 = S[3] - S[4];
+        f32x4 ya, yb;
+        if (op == 0) {
+            ya = (S[0] + s12) + s34;                    // row 0: 1 1 1 1 1 0
+            yb = w4_fma(2.f, d34, d12);                 // row 1: 0 1 -1 2 -2 0
+        } else {
+            ya = w4_fma(4.f, s34, s12);                 // row 2: 0 1 1 4 4 0
+            yb = w4_fma(8.f, d34, d12) + S[5];          // row 3: 0 1 -1 8 -8 1
         }
-        __syncthreads();
-    }
+        const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(p.bias + cb + 8 * rg);
+        ya += bias4; yb += bias4;
+        if (p.lrelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ya[e] = lrelu01(ya[e]); yb[e] = lrelu01(yb[e]); }
+        }
+        const int ox = x0 + 4 * tx + oq, oy = y0 + 4 * ty + 2 * op;
+        if (ox < p.W && cb + 8 * rg < p.cout_store) {
+            if (oy < p.H) *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.H + oy) * p.W + ox) * p.out_stride + cb + 8 * rg) = ya;
+            if (oy + 1 < p.H) *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.H + oy + 1) * p.W + ox) * p.out_stride + cb + 8 * rg) = yb;
+        }
+    };
+    put(0);
+    __syncthreads();
+    get(0); put(1);
+    __syncthreads();
+    get(1); put(2);
+    __syncthreads();
+    get(2); put(3);
+    __syncthreads();
+    get(3);
 }
 
 // OIHW [cout][cin][3][3] -> F(4x4, 3x3) Winograd-domain weights in MFMA A-fragment order:
@@ -344,14 +354,14 @@ void pack_conv_w4(const float *w, int cout, int cin, const int *creal, const int
 {
     const int cp = (cout + 31) / 32 * 32, NB = cp / 32;
     int nchunk = 0;
-    for (int s = 0; s < nseg; ++s) nchunk += (cload[s] + 7) / 8;
+    for (int s = 0; s < nseg; ++s) nchunk += (cload[s] + 15) / 16 * 2;       // whole 16-channel units: an odd chunk count gets a zero chunk
     pk.assign((size_t)nchunk * NB * 36 * 256, 0.f);
     static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
     int chunk = 0, run = 0;
     for (int s = 0; s < nseg; ++s) {
         const int off = coff[s] >= 0 ? coff[s] : run;
-        for (int c0 = 0; c0 < cload[s]; c0 += 8, ++chunk)
+        for (int c0 = 0; c0 < (cload[s] + 15) / 16 * 16; c0 += 8, ++chunk)
             for (int h = 0; h < 2; ++h)
                 for (int e = 0; e < 4; ++e) {
                     const int c = c0 + 4 * h + e;
@@ -386,12 +396,14 @@ int launch_conv_w4(const ConvParamsW &p_in, hipStream_t st)
     int nchunk = 0;
     for (int s = 0; s < p.nseg; ++s) {
         PIV_REQUIRE(p.seg[s].cload % 4 == 0 && p.seg[s].stride % 4 == 0 && p.seg[s].ptr, "conv_wino4: segment %d misaligned", s);
-        nchunk += (p.seg[s].cload + 7) / 8;
+        nchunk += (p.seg[s].cload + 15) / 16 * 2;
     }
     PIV_REQUIRE(nchunk == p.nchunk, "conv_wino4: segments hold %d chunks, weights were packed for %d", nchunk, p.nchunk);
-    const size_t lds = (size_t)2 * W4_PBUF * 16;          // 60 KB: two patch buffers; the epilogue's 48 KB exchange area aliases them
+    const size_t lds = (size_t)2 * W4_PBUF * 16;          // 106 KB: two 16-channel patch buffers; the epilogue's 48 KB exchange area aliases them
     static LdsAttr attr;
     if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_wino4_kernel), (int)lds)) return rc;
+    // One workgroup per (spatial tile, channel block).  Persistent workgroups walking XCD bands of items were measured and were
+    // slower (1369 vs 1235 us on 128->128 at 1024 x 1024: the loop-carried state spills at 168 registers).
     const long blocks = (long)p.B * cdiv(p.H, 16) * cdiv(p.W, 32) * (p.cout_pad / 32);
     PIV_REQUIRE(blocks < (1L << 31), "conv_wino4: grid too large");
     hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)blocks), dim3(768), lds, st, p);

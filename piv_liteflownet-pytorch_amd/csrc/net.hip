@@ -41,7 +41,7 @@ struct ConvW {
     float *wpk_c = nullptr;        // (7 x 1) layers from 32 channels: A fragments of conv_col7_kernel, [4][7][2][64][4]
     float *wpk_w = nullptr;        // 3 x 3 layers: Winograd-domain weights G g G^T in fragment order (conv_wino.hip)
     float *wpk_w4 = nullptr;       // the same for F(4x4, 3x3): 36 planes (conv_wino4.hip)
-    int nchunk_w = 0;
+    int nchunk_w = 0, nchunk_w4 = 0;
 };
 
 struct LevelW {
@@ -194,8 +194,7 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         pack_conv_w(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w);
         rc = upload(net, pw, &out->wpk_w);
         if (rc) return rc;
-        int nchunk4 = 0;
-        pack_conv_w4(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &nchunk4);
+        pack_conv_w4(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w4);
         rc = upload(net, pw, &out->wpk_w4);
         if (rc) return rc;
     }
@@ -608,9 +607,11 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         q.wpk = cw.wpk_w; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
         q.cout_pad = cw.cout_pad;
         q.B = B; q.H = H; q.W = W; q.nchunk = cw.nchunk_w; q.lrelu = lrelu;
-        // F(4x4, 3x3) from W4_MIN_PIXELS per image up (per image, never a function of the batch): 1.78x fewer matrix instructions
-        if (cw.wpk_w4 && (long)Ho * Wo >= (PIV_KNOB(13) ? (PIV_KNOB(13) < 0 ? (1L << 40) : PIV_KNOB(13)) : W4_MIN_PIXELS)) {
-            q.wpk = cw.wpk_w4;
+        // F(4x4, 3x3) is not used by pivlfn_forward: 1.78x fewer matrix instructions, but its 6x6 transforms, 106 KB of LDS (one
+        // workgroup per CU) and lockstep of 12 waves leave it at 0.98x of F(2x2) on 128->128 and 0.68x on 32->32 at 1024 x 1024
+        // (DESIGN.md 4.2c).  The tools build can switch it in from knob 13 output pixels per image up, for A/B runs of the forward.
+        if (cw.wpk_w4 && PIV_KNOB(13) > 0 && (long)Ho * Wo >= PIV_KNOB(13)) {
+            q.wpk = cw.wpk_w4; q.nchunk = cw.nchunk_w4;
             return launch_conv_w4(q, st);
         }
         return launch_conv_w(q, st);
@@ -718,7 +719,7 @@ int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     q.cout_pad = c->cw.cout_pad;
     q.B = B; q.H = H; q.W = W; q.nchunk = c->cw.nchunk_w; q.lrelu = leaky;
     if (tile == 4) {
-        q.wpk = c->cw.wpk_w4;
+        q.wpk = c->cw.wpk_w4; q.nchunk = c->cw.nchunk_w4;
         return launch_conv_w4(q, st);
     }
     return launch_conv_w(q, st);
