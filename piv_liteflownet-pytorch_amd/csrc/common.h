@@ -181,6 +181,9 @@ bool conv_wino_supports(int KH, int KW, int S, int padY, int padX);
 // (7 x 1) convolution from 32 channels to up to 64 on v_mfma_f32_16x16x4_f32, operands from global memory (conv_head.hip)
 int launch_conv_col7(const float *x, int x_stride, const float *wf, const float *bias, float *out, int out_stride, int cout_store,
                      int single48, int B, int H, int W, hipStream_t st);
+// (1 x 7) convolution 49 -> 49 channels (52 stored lanes), the same way along x (conv_head.hip)
+int launch_conv_row7(const float *x, int x_stride, const float *wf, const float *wf12, const float *bias, float *out, int out_stride,
+                     int B, int H, int W, hipStream_t st);
 int launch_conv_head(const float *x, const float *w, float b0, float b1, const float *res4, float *out4, int B, int H, int W,
                      int k, hipStream_t st);
 

@@ -281,21 +281,31 @@ __global__ __launch_bounds__(256) void conv_head_mfma_kernel(const float *__rest
 // 14 register-resident weight fragments, with no LDS and no barrier, and stores 16-byte channel quads straight from the
 // accumulator layout.  No activation (the reference has none between the two halves of the separable pair).
 template <int TH>
-__global__ __launch_bounds__(256) void conv_col7_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ wf,
+__global__ __launch_bounds__(256, 2) void conv_col7_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ wf,
                                                         const float *__restrict__ bias, float *__restrict__ out, int out_stride,
                                                         int cout_store, int single48, int B, int H, int W)
 {
     constexpr int K = 7, P = 3, NR = TH + 2 * P, AHEAD = 3;
     const int tiles_x = (W + 15) >> 4, tiles_y = (H + TH - 1) / TH;
-    int bid = xcd_remap(blockIdx.x, tiles_x * tiles_y * B);
+    const int ntiles = tiles_x * tiles_y * B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+    // A workgroup takes four consecutive tiles, one after the other, and wave w takes output block (w + i) & 3 of the i-th: in the
+    // 49-channel layer block 3 is channel 48 alone, on the vector unit, a fifth of the work of a matrix block.  With one tile per
+    // workgroup the wave that drew it was done early and its slot stayed empty until the workgroup retired -- two of a CU's four
+    // SIMDs held one working wave instead of two (250 us at 1024 x 1024 for 143 us of MFMA time).  The waves share no LDS and
+    // meet at no barrier: every one runs three matrix blocks and one vector block, in its own order.
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+    int bid = xcd_remap(blockIdx.x, gridDim.x) * 4 + ph;
+    if (bid >= ntiles) break;
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int y0 = ty * TH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int blk = __builtin_amdgcn_readfirstlane(tid >> 6);        // 16-channel output block of this wave
-    const int n16 = lane & 15, kq = lane >> 4;
+    const int blk = (wave + ph) & 3;                                 // 16-channel output block of this wave in this tile
     f32x4h A[K][2];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky)
@@ -373,6 +383,7 @@ __global__ __launch_bounds__(256) void conv_col7_kernel(const float *__restrict_
             if (oy < H) *reinterpret_cast<f32x4h *>(out + ((size_t)(b * H + oy) * W + xs) * out_stride + ch) = acc[i] + b4;
         }
     }
+    }       // tiles of the workgroup
 }
 
 // wf: [4 blocks][7][2][64][4] fragments (net.hip pack_conv), bias: [64]; single48: the layer has 49 output channels and block 3 of
@@ -386,7 +397,168 @@ int launch_conv_col7(const float *x, int x_stride, const float *wf, const float 
     PIV_REQUIRE(!single48 || cout_store == 52, "conv_col7: the 49-channel layer stores 52 lanes (got %d)", cout_store);
     PIV_REQUIRE((long)H * W * x_stride * 4 < (1L << 31), "conv_col7: image exceeds 2 GiB");
     constexpr int TH = 16;
-    hipLaunchKernelGGL((conv_col7_kernel<TH>), dim3(cdiv(W, 16) * cdiv(H, TH) * B), dim3(256), 0, st, x, x_stride, wf, bias, out, out_stride, cout_store, single48, B, H, W);
+    hipLaunchKernelGGL((conv_col7_kernel<TH>), dim3(cdiv(cdiv(W, 16) * cdiv(H, TH) * B, 4)), dim3(256), 0, st, x, x_stride, wf, bias, out, out_stride, cout_store, single48, B, H, W);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+// ---- (1 x 7) distance convolution, 49 -> 49 channels on 52 stored lanes (conv_dist_R.1 of levels 1 and 2,
+// /root/reference/src/models.py:258-261): conv_col7 turned by 90 degrees.  The 16 "pixels" of the matrix instruction are 16 ROWS of
+// one image column; a wave walks along x and every column it loads (13 channel quads: three 16-byte loads of quads kq, kq+4, kq+8
+// and channel 48 on its own) feeds the seven outputs x - 3 .. x + 3 from registers: the shift of a tap is a different accumulator,
+// never a different lane.  7 x 13 = 91 MFMAs per column and 16-channel block (the direct kernel's 64 x 56 padding: 7 x 14 x 2 of
+// twice the size), no LDS, no barrier; the four waves of a workgroup read the same bytes (L1 hits) and own one output block each,
+// block 3 -- channel 48 alone -- on the vector unit.  No activation, bias added.
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv_row7_kernel(const float *__restrict__ x, int x_stride, const float *__restrict__ wf,
+                                                        const float *__restrict__ wf12, const float *__restrict__ bias,
+                                                        float *__restrict__ out, int out_stride, int B, int H, int W,
+                                                        unsigned long long *stamps)
+{
+    constexpr int K = 7, P = 3, NC = TW + 2 * P, AHEAD = 2;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 15) >> 4;
+    const int ntiles = tiles_x * tiles_y * B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+    // four consecutive tiles per workgroup, wave w on block (w + i) & 3 of the i-th: every wave runs three matrix blocks and the
+    // vector block (see conv_col7_kernel)
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+    int bid = xcd_remap(blockIdx.x, gridDim.x) * 4 + ph;
+    if (bid >= ntiles) break;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * TW;
+    const int blk = (wave + ph) & 3;
+#ifdef PIVLFN_STAMPS          // tools build: start of the unit, weights there, first column there, last MFMA issued, end (s_memtime ticks)
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+#define R7_NOW(T) do { __builtin_amdgcn_sched_barrier(0); T = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    if (stamps) R7_NOW(ts0);
+#endif
+    f32x4h A[K][3];
+    float A12[K];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) A[kx][g] = *reinterpret_cast<const f32x4h *>(wf + (((blk * K + kx) * 3 + g) * 64 + lane) * 4);
+        A12[kx] = wf12[(blk * K + kx) * 64 + lane];
+    }
+    const size_t img = (size_t)H * W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)b * img * x_stride), 0,
+                                                                          (unsigned)(((img - 1) * x_stride + 52) * sizeof(float)), 0x00020000);
+    const int row = ty * 16 + n16;
+    const bool rin = row < H;
+    f32x4h acc[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = f32x4h{0.f, 0.f, 0.f, 0.f};
+    f32x4h Bq[NC][3];
+    float B12[NC];
+    // out-of-range columns and rows read zeros (offsets past the descriptor); channel 48 is real in lane group kq = 0 only
+#define ROW_LOAD(CI)                                                                              \
+    do {                                                                                          \
+        const int c_ = x0 - P + (CI);                                                             \
+        const bool in_ = rin & (c_ >= 0) & (c_ < W);                                              \
+        const unsigned pix_ = (unsigned)((row * W + c_) * x_stride) * 4u;                         \
+        const unsigned off_ = in_ ? pix_ + 16u * kq : 0x80000000u;                                \
+        const unsigned o12_ = (in_ & (kq == 0)) ? pix_ + 192u : 0x80000000u;                      \
+        Bq[CI][0] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_, 0, 0)); \
+        Bq[CI][1] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_, 64, 0)); \
+        Bq[CI][2] = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_, 128, 0)); \
+        B12[CI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o12_, 0, 0)); \
+    } while (0)
+#pragma unroll
+    for (int ci = 0; ci < AHEAD; ++ci) ROW_LOAD(ci);
+#ifdef PIVLFN_STAMPS
+    if (stamps) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); R7_NOW(ts1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); R7_NOW(ts2); }
+#endif
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        if (ci + AHEAD < NC) ROW_LOAD(ci + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk == 3) {
+            // channel 48 on the vector unit: the fragment registers hold its weights (replicated over the slots at pack time); every
+            // lane multiplies its 13 channels of the column, the four channel groups of a pixel are added across lanes at the end
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int xo = ci - kx;
+                if (xo < 0 || xo >= TW) continue;
+                float e = acc[xo][0];
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e = fmaf(A[kx][g][j], Bq[ci][g][j], e);
+                e = fmaf(A12[kx], B12[ci], e);
+                acc[xo][0] = e;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {       // consecutive MFMAs target different accumulators
+                        const int xo = ci - kx;
+                        if (xo < 0 || xo >= TW) continue;
+                        acc[xo] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kx][g][j], Bq[ci][g][j], acc[xo], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int xo = ci - kx;
+                if (xo < 0 || xo >= TW) continue;
+                acc[xo] = __builtin_amdgcn_mfma_f32_16x16x4f32(A12[kx], B12[ci], acc[xo], 0, 0, 0);
+            }
+        }
+    }
+#undef ROW_LOAD
+#ifdef PIVLFN_STAMPS
+    if (stamps) R7_NOW(ts3);
+#endif
+    if (blk == 3) {
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            float e = acc[i][0];
+            e = e + __shfl_xor(e, 16);
+            e = e + __shfl_xor(e, 32);
+            acc[i] = f32x4h{e, 0.f, 0.f, 0.f};
+        }
+    }
+    // lane holds output channels 16 blk + 4 kq .. + 3 of row `row` for every column of the tile: one 16-byte store per column
+    const int ch = 16 * blk + 4 * kq;
+    if (rin && ch < 52) {
+        const f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
+        float *orow = out + ((size_t)(b * H + row) * W + x0) * out_stride + ch;
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+            if (x0 + i < W) *reinterpret_cast<f32x4h *>(orow + (size_t)i * out_stride) = acc[i] + b4;
+    }
+#ifdef PIVLFN_STAMPS
+    if (stamps && lane == 0) {
+        unsigned long long *o = stamps + ((size_t)(blockIdx.x * 4 + wave) * 4 + ph) * 8;
+        unsigned long long ts4;
+        R7_NOW(ts4);
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts4; o[5] = blk;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        o[6] = hw;
+    }
+#endif
+    }       // tiles of the workgroup
+}
+
+// wf: [4 blocks][7][3][64][4] fragments of channel quads kq + 4 g, wf12: [4][7][64] = channel 48 in lane group 0 (net.hip pack_conv);
+// block 3 of both holds output channel 48's weights replicated over the slots; bias: [64]
+int launch_conv_row7(const float *x, int x_stride, const float *wf, const float *wf12, const float *bias, float *out, int out_stride,
+                     int B, int H, int W, hipStream_t st)
+{
+    PIV_REQUIRE(x && wf && wf12 && bias && out && B > 0 && H > 0 && W > 0, "conv_row7: bad arguments");
+    PIV_REQUIRE(x_stride % 4 == 0 && x_stride >= 52 && out_stride % 4 == 0 && out_stride >= 52, "conv_row7: 52 stored lanes in and out (strides %d, %d)", x_stride, out_stride);
+    PIV_REQUIRE((long)H * W * x_stride * 4 < (1L << 31), "conv_row7: image exceeds 2 GiB");
+    constexpr int TW = 16;
+    hipLaunchKernelGGL((conv_row7_kernel<TW>), dim3(cdiv(cdiv(W, TW) * cdiv(H, 16) * B, 4)), dim3(256), 0, st, x, x_stride, wf, wf12, bias, out, out_stride, B, H, W,
+                       reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5)));   // tools build only
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }

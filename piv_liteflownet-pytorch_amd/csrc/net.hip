@@ -39,6 +39,7 @@ struct ConvW {
     float scale_x = 1.f;           // 2^-k undoing the weight scale of wpk_x
     void *wtail_x = nullptr;       // 3 x 3 layers whose staged channels end in a 4-lane tail: that chunk with taps folded into K
     float *wpk_c = nullptr;        // (7 x 1) layers from 32 channels: A fragments of conv_col7_kernel, [4][7][2][64][4]
+    float *wpk_r = nullptr, *wpk_r12 = nullptr;   // the (1 x 7) 49 -> 49 layer: A fragments of conv_row7_kernel, [4][7][3][64][4] and [4][7][64]
     float *wpk_w = nullptr;        // 3 x 3 layers: Winograd-domain weights G g G^T in fragment order (conv_wino.hip)
     float *wpk_w4 = nullptr;       // the same for F(4x4, 3x3): 36 planes (conv_wino4.hip)
     int nchunk_w = 0, nchunk_w4 = 0;
@@ -185,6 +186,23 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
                             if (o < cout) pc[((((size_t)blk * 7 + ky) * 2 + hh) * 64 + lane) * 4 + j] = w->data[((size_t)o * 32 + c) * 7 + ky];
                         }
         rc = upload(net, pc, &out->wpk_c);
+        if (rc) return rc;
+    }
+    if (kh == 1 && kw == 7 && cin == 49 && cout == 49 && segs.size() == 1 && segs[0].cload == 52) {   // conv_dist_R.1 of levels 1 and 2
+        std::vector<float> pr((size_t)4 * 7 * 3 * 64 * 4, 0.f), p12((size_t)4 * 7 * 64, 0.f);
+        for (int blk = 0; blk < 4; ++blk)
+            for (int kx = 0; kx < 7; ++kx)
+                for (int lane = 0; lane < 64; ++lane) {
+                    // block 3 = output channel 48 replicated over the slots (the kernel's vector path)
+                    const int o = blk == 3 ? 48 : 16 * blk + (lane & 15), kq = lane >> 4;
+                    for (int g = 0; g < 3; ++g)
+                        for (int j = 0; j < 4; ++j)
+                            pr[((((size_t)blk * 7 + kx) * 3 + g) * 64 + lane) * 4 + j] = w->data[((size_t)o * 49 + 4 * (kq + 4 * g) + j) * 7 + kx];
+                    if (kq == 0) p12[((size_t)blk * 7 + kx) * 64 + lane] = w->data[((size_t)o * 49 + 48) * 7 + kx];
+                }
+        rc = upload(net, pr, &out->wpk_r);
+        if (rc) return rc;
+        rc = upload(net, p12, &out->wpk_r12);
         if (rc) return rc;
     }
     if (kh == 3 && kw == 3) {      // 3 x 3: the Winograd-domain packing (used by the stride-1 call sites)
@@ -470,8 +488,11 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
     p.scratch = c->scratch; p.scratch_floats = KSPLIT_FLOATS;
     // the (7 x 1) distance convolution on >= 256 x 256 images: the kernel pivlfn_forward uses for it in the fp32 mode
     if (c->cw.wpk_c && !res && !leaky && stride == 1 && pad_y == 3 && pad_x == 0 && (long)H * W >= 256 * 256 && p.cout_store % 4 == 0 &&
-        (long)H * W * x_stride * 4 < (1L << 31))
+        (long)H * W * x_stride * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
         return launch_conv_col7(x, x_stride, c->cw.wpk_c, c->cw.bias, y, y_stride, p.cout_store, c->cw.cout == 49, B, H, W, st);
+    if (c->cw.wpk_r && !res && !leaky && stride == 1 && pad_y == 0 && pad_x == 3 && (long)H * W >= 256 * 256 && x_stride >= 52 && y_stride >= 52 &&
+        (long)H * W * x_stride * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
+        return launch_conv_row7(x, x_stride, c->cw.wpk_r, c->cw.wpk_r12, c->cw.bias, y, y_stride, B, H, W, st);
     return launch_conv(p, st);
 }
 
@@ -594,6 +615,10 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         segs.size() == 1 && segs.begin()->cload == 32 && (long)Ho * Wo >= 256 * 256 && cout_store % 4 == 0 &&
         (long)H * W * segs.begin()->stride * 4 < (1L << 31) && cw.cout_pad <= 64)
         return launch_conv_col7(segs.begin()->ptr, segs.begin()->stride, cw.wpk_c, cw.bias, out, out_stride, cout_store, cw.cout == 49, B, H, W, st);
+    if (t_precision == 0 && !res && cw.wpk_r && cw.KH == 1 && cw.KW == 7 && S == 1 && padY == 0 && padX == 3 && !lrelu &&
+        segs.size() == 1 && segs.begin()->cload == 52 && segs.begin()->stride >= 52 && out_stride >= 52 && cout_store == 52 &&
+        (long)Ho * Wo >= 256 * 256 && (long)H * W * segs.begin()->stride * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
+        return launch_conv_row7(segs.begin()->ptr, segs.begin()->stride, cw.wpk_r, cw.wpk_r12, cw.bias, out, out_stride, B, H, W, st);
     // fp32 mode: the 3 x 3 / stride 1 layers by Winograd F(2x2, 3x3) on the fp32 matrix instruction (conv_wino.hip) from a
     // 64 x 64 grid per image up (a 32 x 32 grid is 32 workgroups with the whole K loop each: the split-K direct kernel is faster);
     // the bound is per image, never a function of the batch

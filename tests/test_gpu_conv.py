@@ -60,6 +60,8 @@ CASES = [
     (49, 32, 7, 1, 1, (3, 0), 256, 272, 1),       # conv_dist_R.0 at >= 256 x 256: the streaming matrix-core kernel
     (49, 32, 7, 1, 1, (3, 0), 300, 261, 2),       # ragged, batch 2
     (49, 49, 1, 7, 1, (0, 3), 32, 40, 1),         # conv_dist_R.1
+    (49, 49, 1, 7, 1, (0, 3), 256, 272, 1),       # conv_dist_R.1 at >= 256 x 256: its streaming matrix-core kernel (columns walk along x)
+    (49, 49, 1, 7, 1, (0, 3), 261, 300, 2),       # ragged rows and columns, batch 2
     (25, 25, 1, 5, 1, (0, 2), 16, 32, 1),
     (9, 32, 3, 3, 1, (1, 1), 8, 8, 3),            # conv_dist_R level 5/6
     (2, 32, 7, 7, 1, (3, 3), 32, 48, 1),          # flow head on the matrix-core path

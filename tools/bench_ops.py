@@ -140,7 +140,8 @@ CONV_SHAPES = _level_layers(1, 1024) + _level_layers(2, 512) + _level_layers(3, 
     ("NetC.conv3.2 64->64 @256", 64, 64, 3, 1, 256, 2), ("NetC.conv5.0 s2 96->128", 128, 96, 3, 2, 128, 2),
     ("L1 moduleFeat 1x1 32->128", 128, 32, 1, 1, 1024, 1), ("L1 NetC_ext 1x1 32->64", 64, 32, 1, 1, 1024, 2),
     ("L1 dist 7x1 32->49", 49, 32, (7, 1), 1, 1024, 1),
-    ("L1 dist 1x7 49->49", 49, 52, (1, 7), 1, 1024, 1),
+    ("L1 dist 1x7 49->49", 49, 49, (1, 7), 1, 1024, 1),
+    ("L2 dist 7x1 32->49", 49, 32, (7, 1), 1, 512, 1), ("L2 dist 1x7 49->49", 49, 49, (1, 7), 1, 512, 1),
 ]
 
 
@@ -161,7 +162,9 @@ def bench_conv(args):
         b = torch.randn(co).contiguous()
         h = ctypes.c_void_p()
         _chk(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, kh, kw, ctypes.byref(h)), "create")
-        x = torch.randn(B, n, n, ci, device=dev)
+        xs = -(-ci // 4) * 4                      # stored lanes of the input (zeros behind the real channels)
+        x = torch.randn(B, n, n, xs, device=dev)
+        x[..., ci:] = 0
         no = (n + 2 * (kh // 2) - kh) // s + 1
         mo = (n + 2 * (kw // 2) - kw) // s + 1
         ys = -(-co // 4) * 4
@@ -185,14 +188,14 @@ def bench_conv(args):
             def fn(v=v, y=y, f16io=f16io):
                 lib.pivlfn_tune(1, (v % 1000000) if split else ((v - 100000) >> 1 if v >= 100000 else v))
                 if split:
-                    _chk(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), ci, y.data_ptr(), ys, B, n, n, s, kh // 2, kw // 2, 1, 3 if v >= 3000000 else 6, st), "conv")
+                    _chk(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), xs, y.data_ptr(), ys, B, n, n, s, kh // 2, kw // 2, 1, 3 if v >= 3000000 else 6, st), "conv")
                 elif v >= 100000:
                     if f16io and ci % 8 == 0:
                         _chk(lib.pivlfn_conv2d_nhwc_f16(h, xh.data_ptr(), ci, 1, y.data_ptr(), ys, 1, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
                     else:
-                        _chk(lib.pivlfn_conv2d_nhwc_f16(h, x.data_ptr(), ci, 0, y.data_ptr(), ys, 1 if f16io else 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                        _chk(lib.pivlfn_conv2d_nhwc_f16(h, x.data_ptr(), xs, 0, y.data_ptr(), ys, 1 if f16io else 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
                 else:
-                    _chk(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
+                    _chk(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), xs, y.data_ptr(), ys, None, 0, B, n, n, s, kh // 2, kw // 2, 1, st), "conv")
             tmin, tmed = time_it(fn, n=10 if flop > 2e10 else 30, rounds=4)
             print(f"{name:28s} B={B} variant {v}: min {tmin:9.1f} us  med {tmed:9.1f} us  {flop / tmin / 1e6:7.1f} TFLOP/s (staged K)", flush=True)
         for v in variants[1:]:
