@@ -615,6 +615,171 @@ static int launch_conv_k1(const ConvParams &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
+// ---- 3 x 3 / stride 2 from 32 channels (NetC.conv2.0 32 -> 32 at 1024^2, NetC.conv3.0 32 -> 64 at 512^2) -------------------------
+// The v2 kernel stages 8 channels of its patch per K chunk: 32 of a pixel's 128 bytes, four times over a workgroup's life, and with
+// ~100 patches of 90-270 KB in flight per XCD the line has left that L2 before the next chunk asks for it -- the layer fetched its
+// input 3.3 times (FETCH_SIZE, round 3) and ran at the HBM bound of that traffic.  Here a pixel is fetched once, as one whole line:
+// the patch holds all 32 channels (17 x 33 pixels for an 8 x 16 output tile: 2 rows x 16 columns per wave), the weights of the whole
+// layer stay in LDS for the workgroup's life, a workgroup walks tiles blockIdx.x, + gridDim.x, ... with the next tile's patch
+// prefetched into registers under the current tile's MFMAs (one workgroup per CU: the patch and the weights take 118-155 KB).
+// K order per output: the four 8-channel groups outer, taps inner, as in the v2 kernel.
+// (Measured and dropped: the weight fragments straight from global memory, ten steps ahead of their use, so that the patch alone
+// is in LDS and two workgroups fit a CU -- 291 us against 119 on 32 -> 32 at 1024^2: the fragment loads queue behind the next
+// patch's HBM loads in the in-order wait counter, and 36 KB of fragments per tile and wave do not stay in L1.)
+constexpr int S2_PIXP = 36, S2_PH = 17, S2_PW = 33, S2_NPIX = S2_PH * S2_PW, S2_PMAX = 18;     // 561 x 8 quads <= 256 x 18
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_s2c32_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 32 * NT;
+    float *patch = smem;
+    float *wts = smem + S2_NPIX * S2_PIXP;
+    const int tiles_x = (p.Wo + 15) >> 4, tiles_y = (p.Ho + 7) >> 3;
+    const int ntiles = tiles_x * tiles_y * p.B;
+    const int n0 = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, hh = lane >> 5, prow = (lane >> 4) & 1, pcol = lane & 15;
+    if ((int)blockIdx.x >= ntiles) return;
+    {   // the layer's weights for this block of output channels -> LDS, once: [group][tap][half][BN][4]
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + n0;
+        for (int idx = tid; idx < 4 * 9 * 2 * BN; idx += 256)
+            reinterpret_cast<f32x4 *>(wts)[idx] = wsrc[(idx / BN) * p.cout_pad + (idx % BN)];
+    }
+    const int abase = ((2 * (wave * 2 + prow)) * S2_PW + 2 * pcol) * S2_PIXP + hh * 4;
+    const int bbase = (hh * BN + row) * 4;
+    const float *sp = p.seg[0].ptr;
+    const int sst = p.seg[0].stride;
+    const int q = tid & 7, pix0 = tid >> 3;             // staging slot i: quad q of patch pixel pix0 + 32 i
+    f32x4 bias4[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias4[n][g] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + n * 32 + 8 * g + 4 * hh);
+    // patch coordinates of this thread's slots (the same for every tile): py << 8 | px, 0xffff = past the patch
+    unsigned pyx[S2_PMAX];
+#pragma unroll
+    for (int i = 0; i < S2_PMAX; ++i) {
+        const int pix = pix0 + 32 * i;
+        const int py = pix / S2_PW, px = pix - py * S2_PW;
+        pyx[i] = pix < S2_NPIX ? (unsigned)(py << 8 | px) : 0xffffu;
+    }
+
+    f32x4 pr[S2_PMAX];
+    // Buffer loads through a descriptor that starts at the first image row of the tile's patch: zero padding and slots past the patch
+    // carry an out-of-range offset (no branch around a load), and one image may be of any size.
+#define S2_LOAD(T)                                                                                \
+    do {                                                                                          \
+        int t_ = (T);                                                                             \
+        const int tx_ = t_ % tiles_x;                                                             \
+        t_ /= tiles_x;                                                                            \
+        const int b_ = t_ / tiles_y;                                                              \
+        const int ix0_ = tx_ * 32 - 1, iy0_ = (t_ - b_ * tiles_y) * 16 - 1;                       \
+        const int row0_ = min(max(iy0_, 0), p.H - 1);                                             \
+        const size_t left_ = (size_t)(p.H - row0_) * p.W - 1;                                     \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                     \
+            const_cast<float *>(sp + ((size_t)b_ * p.H * p.W + (size_t)row0_ * p.W) * sst), 0,    \
+            (unsigned)min((left_ * sst + 32) * 4, (size_t)0x7fffffff), 0x00020000);               \
+        _Pragma("unroll") for (int i = 0; i < S2_PMAX; ++i) {                                     \
+            const int iy_ = iy0_ + (int)(pyx[i] >> 8), ix_ = ix0_ + (int)(pyx[i] & 255u);         \
+            const bool ok_ = (pyx[i] != 0xffffu) & (iy_ >= 0) & (iy_ < p.H) & (ix_ >= 0) & (ix_ < p.W); \
+            const unsigned off_ = ok_ ? (unsigned)((iy_ - row0_) * p.W + ix_) * (unsigned)(sst * 4) + 16u * q : C2OOB; \
+            pr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)off_, 0, 0)); \
+        }                                                                                         \
+    } while (0)
+
+    S2_LOAD(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();          // the previous tile's operand reads are done (first pass: the weights are written)
+#pragma unroll
+        for (int i = 0; i < S2_PMAX; ++i)
+            if (pyx[i] != 0xffffu) *reinterpret_cast<f32x4 *>(patch + (pix0 + 32 * i) * S2_PIXP + 4 * q) = pr[i];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) S2_LOAD(tile + gridDim.x);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        // 36 steps (group c, tap): one 16-byte read of either operand feeds four MFMAs.  The reads run S2_D steps ahead of their
+        // MFMAs, pinned by scheduling fences: with one wave per SIMD nothing else covers an LDS round trip (left to the compiler the
+        // reads sit right in front of their use).  Measured: the same 120 us on 32 -> 32 at 1024^2 either way -- a tile takes
+        // 17.8 k cycles for 9.2 k of matrix work; what the other half is has not been taken apart yet.
+        constexpr int S2_D = 3;
+        f32x4 av[36], bv[36][NT];
+#define S2_READ(S)                                                                                \
+        do {                                                                                      \
+            const int c_ = (S) / 9, tap_ = (S) % 9, ky_ = tap_ / 3, kx_ = tap_ % 3;               \
+            av[S] = *reinterpret_cast<const f32x4 *>(patch + abase + (ky_ * S2_PW + kx_) * S2_PIXP + 8 * c_); \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n)                                        \
+                bv[S][n] = *reinterpret_cast<const f32x4 *>(wts + ((c_ * 9 + tap_) * 2 * BN) * 4 + bbase + n * 128); \
+        } while (0)
+#pragma unroll
+        for (int s_ = 0; s_ < S2_D; ++s_) S2_READ(s_);
+#pragma unroll
+        for (int s_ = 0; s_ < 36; ++s_) {
+            if (s_ + S2_D < 36) S2_READ(s_ + S2_D);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[s_][n][j], av[s_][j], acc[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef S2_READ
+        // epilogue: lane & 31 = pixel (2 rows x 16 columns of the wave), registers 4 g .. 4 g + 3 = channels 8 g + 4 hh + {0..3}
+        int t_ = tile;
+        const int tx = t_ % tiles_x;
+        t_ /= tiles_x;
+        const int b = t_ / tiles_y;
+        const int oy = (t_ - b * tiles_y) * 8 + wave * 2 + prow, ox = tx * 16 + pcol;
+        if (oy < p.Ho && ox < p.Wo) {
+            float *orow = p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.out_stride + n0;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (n0 + n * 32 + 8 * g + 4 * hh >= p.cout_store) continue;
+                    f32x4 v = {acc[n][4 * g + 0], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]};
+                    v += bias4[n][g];
+                    if (p.lrelu) {
+                        v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                    }
+                    *reinterpret_cast<f32x4 *>(orow + n * 32 + 8 * g + 4 * hh) = v;
+                }
+        }
+    }
+#undef S2_LOAD
+}
+
+// Applies to: 3 x 3, stride 2, pad 1, one source of exactly 32 channels, 32 or 64 output channels, no residual, and (per image, never
+// a function of the batch) at least 256 tiles of 8 x 16 outputs.
+static int launch_conv_s2(const ConvParams &p_in, hipStream_t st)
+{
+    const ConvParams &p = p_in;
+    if (p.KH != 3 || p.KW != 3 || p.S != 2 || p.padY != 1 || p.padX != 1 || p.nseg != 1 || p.seg[0].cload != 32 || p.nchunk != 4 || p.tail ||
+        p.res || (p.cout_pad != 32 && p.cout_pad != 64) || (PIV_KNOB(1) & 4194304))
+        return -1;
+    if ((long)cdiv(p.Wo, 16) * cdiv(p.Ho, 8) < 256) return -1;
+    if ((size_t)17 * p.W * p.seg[0].stride * 4 >= 0x7fffffffull) return -1;       // one patch inside a descriptor's 2 GiB
+    const int nt = p.cout_pad / 32;
+    const size_t lds = ((size_t)S2_NPIX * S2_PIXP + (size_t)4 * 9 * 2 * 32 * nt * 4) * sizeof(float);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long tiles = (long)cdiv(p.Wo, 16) * cdiv(p.Ho, 8) * p.B;
+    const dim3 grid((unsigned)std::min<long>(tiles, cus), 1);
+    static LdsAttr attr1, attr2;
+    if (nt == 1) {
+        if (int rc = ensure_dyn_lds(attr1, reinterpret_cast<const void *>(conv_s2c32_kernel<1>), 160 * 1024)) return rc;
+        hipLaunchKernelGGL((conv_s2c32_kernel<1>), grid, dim3(256), lds, st, p);
+    } else {
+        if (int rc = ensure_dyn_lds(attr2, reinterpret_cast<const void *>(conv_s2c32_kernel<2>), 160 * 1024)) return rc;
+        hipLaunchKernelGGL((conv_s2c32_kernel<2>), grid, dim3(256), lds, st, p);
+    }
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
 // (Measured and dropped in round 2: a dedicated streaming kernel for the HBM-bound 1x1 layers -- NetC_ext 32 -> 64, moduleFeat
 // 32 -> 128 -- with the whole weight matrix resident in LDS, operands read straight from global memory one pixel run ahead and no
 // barriers: 193.7 vs 195.8 us (moduleFeat, level 1) and 216.7 vs 235.3 us (NetC_ext) against this kernel's 16-row tiles, and no
@@ -717,6 +882,8 @@ int launch_conv(const ConvParams &p, hipStream_t st)
     if (!(PIV_KNOB(1) & 2)) {               // shipped path: v2 (register prefetch); knob bit 1 forces v1 for A/B
         const int rk = launch_conv_k1(p, st);
         if (rk >= 0) return rk;
+        const int rs2 = launch_conv_s2(p, st);
+        if (rs2 >= 0) return rs2;
         const int rc = launch_conv2(p, st);
         if (rc >= 0) return rc;
     }

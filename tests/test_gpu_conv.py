@@ -50,6 +50,8 @@ CASES = [
     (32, 3, 7, 7, 1, (3, 3), 40, 72, 2),          # NetC.conv1
     (32, 32, 3, 3, 2, (1, 1), 64, 96, 1),         # NetC stride-2
     (64, 32, 3, 3, 2, (1, 1), 33, 47, 1),         # odd sizes
+    (32, 32, 3, 3, 2, (1, 1), 262, 530, 1),       # NetC.conv2.0 at >= 256 tiles of 8 x 16 outputs: the whole-line stride-2 kernel, ragged edges
+    (64, 32, 3, 3, 2, (1, 1), 261, 529, 2),       # NetC.conv3.0 on the same kernel (two channel blocks per wave), odd input size, batch 2
     (96, 96, 3, 3, 1, (1, 1), 24, 40, 1),
     (128, 49, 3, 3, 1, (1, 1), 32, 64, 1),        # conv_M.0
     (64, 128, 3, 3, 1, (1, 1), 19, 35, 2),

@@ -75,5 +75,10 @@ int main()
     run<2, 32>(src, dst, ticks, 512, "32x32x2, 2 waves per SIMD");
     run<4, 32>(src, dst, ticks, 512, "32x32x2, 2 waves per SIMD");
     run<4, 32>(src, dst, ticks, 256, "32x32x2, 1 wave per SIMD");
+    run<2, 32>(src, dst, ticks, 256, "32x32x2, 1 wave per SIMD");
+    run<1, 32>(src, dst, ticks, 256, "32x32x2, 1 wave per SIMD");
+    run<1, 16>(src, dst, ticks, 256, "16x16x4, 1 wave per SIMD");
+    run<2, 16>(src, dst, ticks, 256, "16x16x4, 1 wave per SIMD");
+    run<4, 16>(src, dst, ticks, 256, "16x16x4, 1 wave per SIMD");
     return 0;
 }
