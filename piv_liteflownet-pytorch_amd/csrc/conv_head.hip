@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256, 3) void conv_head4_kernel(const float *__restr
 //   * the T tile goes through LDS (8 rows x 64 columns x 16 slots at a time) for the diagonal sum, bias and residual; output in the
 //     4-lane flow layout.
 using f32x4h = __attribute__((ext_vector_type(4))) float;
+using u32x4h = __attribute__((ext_vector_type(4))) unsigned int;
 template <int K, int TH>
 __global__ __launch_bounds__(256) void conv_head_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                              float b0, float b1, const float *__restrict__ res4,
@@ -292,10 +293,10 @@ __global__ __launch_bounds__(256, 2) void conv_col7_kernel(const float *__restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kq = lane >> 4;
     // A workgroup takes four consecutive tiles, one after the other, and wave w takes output block (w + i) & 3 of the i-th: in the
-    // 49-channel layer block 3 is channel 48 alone, on the vector unit, a fifth of the work of a matrix block.  With one tile per
-    // workgroup the wave that drew it was done early and its slot stayed empty until the workgroup retired -- two of a CU's four
-    // SIMDs held one working wave instead of two (250 us at 1024 x 1024 for 143 us of MFMA time).  The waves share no LDS and
-    // meet at no barrier: every one runs three matrix blocks and one vector block, in its own order.
+    // 49-channel layer block 3 is channel 48 alone, on the vector unit, a fraction of the matrix work of the other blocks.  With one
+    // tile per workgroup the wave that drew it left its slot empty until the workgroup retired.  The waves share no LDS and meet at
+    // no barrier: every one runs three matrix blocks and one vector block, in its own order.  (Persistent workgroups, two per CU,
+    // walking the tiles pass by pass: no better -- 222 / 330 us against 225 / 312 at 1024 x 1024.)
 #pragma unroll 1
     for (int ph = 0; ph < 4; ++ph) {
     int bid = xcd_remap(blockIdx.x, gridDim.x) * 4 + ph;
@@ -316,9 +317,22 @@ __global__ __launch_bounds__(256, 2) void conv_col7_kernel(const float *__restri
                                                                           (unsigned)(((img - 1) * x_stride + 32) * sizeof(float)), 0x00020000);
     const int xs = tx * 16 + n16;
     const bool xin = xs < W;
+    // lane holds output channels 16 blk + 4 kq .. + 3 of column xs for every row.  The accumulators start from the bias, and a row is
+    // stored as soon as its seventh tap is in (row ri - 6 after input row ri): one 16-byte buffer store straight from the accumulator,
+    // under the next rows' MFMAs.  (An epilogue of `store(acc[i] + bias)` put every sum into one temporary, and the wait protecting a
+    // store's source registers made each of the 16 stores wait for the one before it: a third of the workgroup's life.)
+    const int ch = 16 * blk + 4 * kq;
+    const bool vec48 = blk == 3 && single48;
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * img * out_stride, 0,
+                                                                           (unsigned)(((img - 1) * out_stride + cout_store) * sizeof(float)), 0x00020000);
+    const bool chin = xin && ch < cout_store;
     f32x4h acc[TH];
+    {
+        f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
+        if (vec48 && kq != 0) b4 = f32x4h{0.f, 0.f, 0.f, 0.f};      // the vector path adds its four lane groups at the end: the bias once
 #pragma unroll
-    for (int i = 0; i < TH; ++i) acc[i] = f32x4h{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TH; ++i) acc[i] = b4;
+    }
     f32x4h Bq[NR][2];
 #define COL_LOAD(RI)                                                                              \
     do {                                                                                          \
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_col7_kernel(const float *__restri
     for (int ri = 0; ri < NR; ++ri) {
         if (ri + AHEAD < NR) COL_LOAD(ri + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
-        if (blk == 3 && single48) {
+        if (vec48) {
             // 49 output channels = three 16-channel blocks + ONE channel: a fourth MFMA block would spend 15 of its 16 rows on
             // padding.  The fourth wave takes channel 48 on the vector unit instead: its fragment registers hold that channel's
             // weights (replicated over the slots at pack time), every lane multiplies its 8 channels of the row, the four
@@ -362,27 +376,20 @@ __global__ __launch_bounds__(256, 2) void conv_col7_kernel(const float *__restri
                         acc[yi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ky][h][j], Bq[ri][h][j], acc[yi], 0, 0, 0);
                     }
         }
+        if (ri >= K - 1) {                     // output row ri - 6 is complete
+            const int yi = ri - (K - 1);
+            if (vec48) {                       // channel groups kq = 0..3 of a pixel live in lanes l, l+16, l+32, l+48: add them (fixed order)
+                float e = acc[yi][0];
+                e = e + __shfl_xor(e, 16);
+                e = e + __shfl_xor(e, 32);
+                acc[yi] = f32x4h{e, 0.f, 0.f, 0.f};
+            }
+            const int oy = y0 + yi;
+            const unsigned off = (chin && oy < H) ? (unsigned)((oy * W + xs) * out_stride + ch) * 4u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, acc[yi]), rso, (int)off, 0, 0);
+        }
     }
 #undef COL_LOAD
-    if (blk == 3 && single48) {       // channel groups kq = 0..3 of a pixel live in lanes l, l+16, l+32, l+48: add them (fixed order)
-#pragma unroll
-        for (int i = 0; i < TH; ++i) {
-            float e = acc[i][0];
-            e = e + __shfl_xor(e, 16);
-            e = e + __shfl_xor(e, 32);
-            acc[i] = f32x4h{e, 0.f, 0.f, 0.f};
-        }
-    }
-    // lane holds output channels 16 blk + 4 kq .. + 3 of column xs for every row: one 16-byte store per row
-    const int ch = 16 * blk + 4 * kq;
-    if (xin && ch < cout_store) {
-        const f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
-#pragma unroll
-        for (int i = 0; i < TH; ++i) {
-            const int oy = y0 + i;
-            if (oy < H) *reinterpret_cast<f32x4h *>(out + ((size_t)(b * H + oy) * W + xs) * out_stride + ch) = acc[i] + b4;
-        }
-    }
     }       // tiles of the workgroup
 }
 
@@ -415,14 +422,13 @@ __global__ __launch_bounds__(256, 2) void conv_row7_kernel(const float *__restri
                                                         float *__restrict__ out, int out_stride, int B, int H, int W,
                                                         unsigned long long *stamps)
 {
-    constexpr int K = 7, P = 3, NC = TW + 2 * P, AHEAD = 2;
+    constexpr int K = 7, P = 3, NC = TW + 2 * P, AHEAD = 3;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 15) >> 4;
     const int ntiles = tiles_x * tiles_y * B;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kq = lane >> 4;
-    // four consecutive tiles per workgroup, wave w on block (w + i) & 3 of the i-th: every wave runs three matrix blocks and the
-    // vector block (see conv_col7_kernel)
+    // four consecutive tiles per workgroup, wave w on block (w + i) & 3 of the i-th (see conv_col7_kernel)
 #pragma unroll 1
     for (int ph = 0; ph < 4; ++ph) {
     int bid = xcd_remap(blockIdx.x, gridDim.x) * 4 + ph;
@@ -451,9 +457,19 @@ __global__ __launch_bounds__(256, 2) void conv_row7_kernel(const float *__restri
                                                                           (unsigned)(((img - 1) * x_stride + 52) * sizeof(float)), 0x00020000);
     const int row = ty * 16 + n16;
     const bool rin = row < H;
+    // lane holds output channels 16 blk + 4 kq .. + 3 of row `row` for every column of the tile; accumulators start from the bias and
+    // column ci - 6 is stored, straight from its accumulator, as soon as input column ci is in (see conv_col7_kernel)
+    const int ch = 16 * blk + 4 * kq;
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * img * out_stride, 0,
+                                                                           (unsigned)(((img - 1) * out_stride + 52) * sizeof(float)), 0x00020000);
+    const bool chin = rin && ch < 52;
     f32x4h acc[TW];
+    {
+        f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
+        if (blk == 3 && kq != 0) b4 = f32x4h{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < TW; ++i) acc[i] = f32x4h{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TW; ++i) acc[i] = b4;
+    }
     f32x4h Bq[NC][3];
     float B12[NC];
     // out-of-range columns and rows read zeros (offsets past the descriptor); channel 48 is real in lane group kq = 0 only
@@ -511,29 +527,23 @@ __global__ __launch_bounds__(256, 2) void conv_row7_kernel(const float *__restri
                 acc[xo] = __builtin_amdgcn_mfma_f32_16x16x4f32(A12[kx], B12[ci], acc[xo], 0, 0, 0);
             }
         }
+        if (ci >= K - 1) {                     // output column ci - 6 is complete
+            const int xo = ci - (K - 1);
+            if (blk == 3) {
+                float e = acc[xo][0];
+                e = e + __shfl_xor(e, 16);
+                e = e + __shfl_xor(e, 32);
+                acc[xo] = f32x4h{e, 0.f, 0.f, 0.f};
+            }
+            const int ox = x0 + xo;
+            const unsigned off = (chin && ox < W) ? (unsigned)((row * W + ox) * out_stride + ch) * 4u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, acc[xo]), rso, (int)off, 0, 0);
+        }
     }
 #undef ROW_LOAD
 #ifdef PIVLFN_STAMPS
     if (stamps) R7_NOW(ts3);
 #endif
-    if (blk == 3) {
-#pragma unroll
-        for (int i = 0; i < TW; ++i) {
-            float e = acc[i][0];
-            e = e + __shfl_xor(e, 16);
-            e = e + __shfl_xor(e, 32);
-            acc[i] = f32x4h{e, 0.f, 0.f, 0.f};
-        }
-    }
-    // lane holds output channels 16 blk + 4 kq .. + 3 of row `row` for every column of the tile: one 16-byte store per column
-    const int ch = 16 * blk + 4 * kq;
-    if (rin && ch < 52) {
-        const f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
-        float *orow = out + ((size_t)(b * H + row) * W + x0) * out_stride + ch;
-#pragma unroll
-        for (int i = 0; i < TW; ++i)
-            if (x0 + i < W) *reinterpret_cast<f32x4h *>(orow + (size_t)i * out_stride) = acc[i] + b4;
-    }
 #ifdef PIVLFN_STAMPS
     if (stamps && lane == 0) {
         unsigned long long *o = stamps + ((size_t)(blockIdx.x * 4 + wave) * 4 + ph) * 8;
