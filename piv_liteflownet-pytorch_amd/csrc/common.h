@@ -103,6 +103,7 @@ struct ConvParams {
     int KH, KW, S, padY, padX;
     int nchunk;         // K chunks of 8 input channels over all segments (the last one may be a 4-channel tail)
     int tail;           // 1 when the last chunk is a 4-channel tail (last source has cload % 8 == 4)
+    int cin_real;       // real input channels of the layer (the weights of padding lanes are zero); 0 = not stated
     int lrelu;
     // split-K for layers with too few tiles to fill the chip (the coarse pyramid levels): gridDim.z workgroups share a tile,
     // each contracts a contiguous range of K chunks into scratch[z][pixel][cout_pad]; conv_splitk_reduce_kernel adds the

@@ -615,6 +615,132 @@ static int launch_conv_k1(const ConvParams &p, hipStream_t st)
     return PIVLFN_OK;
 }
 
+// ---- NetC.conv1 (7 x 7, 3 -> 32) with the taps packed into K -----------------------------------------------------------------
+// conv_k1 contracts the 4-lane padded pixel per tap: two MFMAs (k = 2 each) of which the second carries one real channel -- 98
+// MFMAs per 32 pixels for 147 real products per output.  Here the patch is stored in LDS with 3 floats per pixel, so the 21
+// (tap, channel) slots of one kernel row are 21 consecutive floats: K runs over (row ky, slot pair j) and a lane half reads slot
+// 2 j + hh with one immediate offset -- 7 x 11 = 77 MFMAs (the 22nd slot of a row reads the next pixel's first channel against a zero
+// weight).  The 77 weight fragments stay in registers for the life of the persistent workgroup (no LDS reads for them), the patch is
+// 6.5 KB: three workgroups per CU.  K order: rows, then slot pairs (conv_k1: taps, then channel pairs).
+constexpr int C3_PW = 38, C3_PITCH = 116, C3_PH = 14;         // patch of an 8 x 32 tile, floats per patch row (38 x 3 + the pad slot)
+
+__global__ __launch_bounds__(256, 3) void conv_c3k7_kernel(const ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float patch[C3_PH * C3_PITCH + 4];
+    constexpr int TH = 8;
+    const int tiles_x = (p.Wo + 31) >> 5, tiles_y = (p.Ho + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * p.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = lane & 31, hh = lane >> 5;
+    if ((int)blockIdx.x >= ntiles) return;
+    // weight fragments: slot s = 3 kx + c of row ky is wpk[((ky * 7 + kx) * 2 + (c >> 1)) * cout_pad + n][c & 1] (net.hip pack_conv,
+    // 4-channel tail layout); slot 21 is the pad
+    float wq[7][11];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int s_ = 2 * j + hh;
+            const int kx = s_ / 3, c = s_ - 3 * kx;
+            wq[ky][j] = s_ < 21 ? p.wpk[(((size_t)(ky * 7 + kx) * 2 + (c >> 1)) * p.cout_pad + row) * 4 + (c & 1)] : 0.f;
+        }
+    for (int i = tid; i < C3_PH; i += 256) { patch[i * C3_PITCH + 114] = 0.f; patch[i * C3_PITCH + 115] = 0.f; }     // pad slots: finite
+    const f32x4 bias4[4] = {*reinterpret_cast<const f32x4 *>(p.bias + 4 * hh), *reinterpret_cast<const f32x4 *>(p.bias + 8 + 4 * hh),
+                            *reinterpret_cast<const f32x4 *>(p.bias + 16 + 4 * hh), *reinterpret_cast<const f32x4 *>(p.bias + 24 + 4 * hh)};
+    const float *sp = p.seg[0].ptr;
+    const int sst = p.seg[0].stride;
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) abase[m] = (wave * 2 + m) * C3_PITCH + row * 3 + hh;
+    f32x4 pr[3];
+#define C3_LOAD(T)                                                                                \
+    do {                                                                                          \
+        int t_ = (T);                                                                             \
+        const int tx_ = t_ % tiles_x;                                                             \
+        t_ /= tiles_x;                                                                            \
+        const int b_ = t_ / tiles_y;                                                              \
+        const int ix0_ = tx_ * 32 - 3, iy0_ = (t_ - b_ * tiles_y) * TH - 3;                       \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
+            const int pix_ = tid + 256 * i;                                                       \
+            const int py_ = pix_ / C3_PW, px_ = pix_ - py_ * C3_PW;                               \
+            const int iy_ = iy0_ + py_, ix_ = ix0_ + px_;                                         \
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                       \
+            if (pix_ < C3_PH * C3_PW && iy_ >= 0 && iy_ < p.H && ix_ >= 0 && ix_ < p.W)           \
+                v = *reinterpret_cast<const f32x4 *>(sp + ((size_t)(b_ * p.H + iy_) * p.W + ix_) * sst); \
+            pr[i] = v;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+    C3_LOAD(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();          // the previous tile's operand reads are done
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pix = tid + 256 * i;
+            if (pix < C3_PH * C3_PW) {
+                const int py = pix / C3_PW, px = pix - py * C3_PW;
+                float *d = patch + py * C3_PITCH + px * 3;
+                d[0] = pr[i][0]; d[1] = pr[i][1]; d[2] = pr[i][2];
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) C3_LOAD(tile + gridDim.x);
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                float a[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[m] = patch[abase[m] + ky * C3_PITCH + 2 * j];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[ky][j], a[m], acc[m], 0, 0, 0);
+            }
+        int t_ = tile;
+        const int tx = t_ % tiles_x;
+        t_ /= tiles_x;
+        const int b = t_ / tiles_y;
+        const int x0 = tx * 32, y0 = (t_ - b * tiles_y) * TH;
+        const int ox = x0 + row;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = y0 + wave * 2 + m;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            float *orow = p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.out_stride;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (8 * g + 4 * hh >= p.cout_store) continue;
+                f32x4 v = {acc[m][4 * g + 0], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+                v += bias4[g];
+                if (p.lrelu) {
+                    v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                }
+                *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * hh) = v;
+            }
+        }
+    }
+#undef C3_LOAD
+}
+
+// Applies to: 7 x 7, stride 1, pad 3, one source of 3 real channels on 4 lanes, 32 output channels, no residual, >= 1024 tiles
+static int launch_conv_c3k7(const ConvParams &p, hipStream_t st)
+{
+    if (p.KH != 7 || p.KW != 7 || p.S != 1 || p.padY != 3 || p.padX != 3 || p.nseg != 1 || p.seg[0].cload != 4 || p.nchunk != 1 || !p.tail ||
+        p.res || p.cout_pad != 32 || p.cin_real != 3 || (PIV_KNOB(1) & 134217728))
+        return -1;
+    const long tiles = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B;
+    if ((long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) < 512) return -1;             // per image: never a function of the batch
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(conv_c3k7_kernel, dim3((unsigned)std::min<long>(tiles, 3L * cus)), dim3(256), 0, st, p);
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
 // ---- 3 x 3 / stride 2 from 32 channels (NetC.conv2.0 32 -> 32 at 1024^2, NetC.conv3.0 32 -> 64 at 512^2) -------------------------
 // The v2 kernel stages 8 channels of its patch per K chunk: 32 of a pixel's 128 bytes, four times over a workgroup's life, and with
 // ~100 patches of 90-270 KB in flight per XCD the line has left that L2 before the next chunk asks for it -- the layer fetched its
@@ -880,6 +1006,8 @@ int launch_conv(const ConvParams &p, hipStream_t st)
     for (int s = 0; s < p.nseg; ++s)
         PIV_REQUIRE(p.seg[s].cload % 4 == 0 && p.seg[s].stride % 4 == 0 && p.seg[s].ptr, "conv: segment %d misaligned", s);
     if (!(PIV_KNOB(1) & 2)) {               // shipped path: v2 (register prefetch); knob bit 1 forces v1 for A/B
+        const int rc3 = launch_conv_c3k7(p, st);
+        if (rc3 >= 0) return rc3;
         const int rk = launch_conv_k1(p, st);
         if (rk >= 0) return rk;
         const int rs2 = launch_conv_s2(p, st);

@@ -31,7 +31,7 @@ void pack_conv_w4(const float *w, int cout, int cin, const int *creal, const int
 
 struct ConvW {
     float *wpk = nullptr, *bias = nullptr;
-    int cout = 0, cout_pad = 0, KH = 0, KW = 0, nchunk = 0, tail = 0;
+    int cout = 0, cout_pad = 0, KH = 0, KW = 0, nchunk = 0, tail = 0, cin = 0;
     void *wpk_h = nullptr;         // fp16 packing for conv_f16.hip (K chunks of 16 channels)
     int nchunk_h = 0;
     void *wpk_x = nullptr;         // three-piece fp16 packing for conv_split.hip (fp32 by exact splitting); nullptr = unsupported geometry
@@ -160,7 +160,7 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         run += s.creal;
     }
     for (int n = 0; n < cout; ++n) bias[n] = b->data[n];
-    out->cout = cout; out->cout_pad = cp; out->KH = kh; out->KW = kw; out->nchunk = nchunk; out->tail = tail;
+    out->cout = cout; out->cout_pad = cp; out->KH = kh; out->KW = kw; out->nchunk = nchunk; out->tail = tail; out->cin = cin;
     int rc = upload(net, pk, &out->wpk);
     if (rc) return rc;
     {   // the fp16 packing of the same layer (optional reduced-precision mode)
@@ -484,7 +484,7 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
     p.B = B; p.H = H; p.W = W; p.KH = c->cw.KH; p.KW = c->cw.KW; p.S = stride; p.padY = pad_y; p.padX = pad_x;
     p.Ho = (H + 2 * pad_y - c->cw.KH) / stride + 1;
     p.Wo = (W + 2 * pad_x - c->cw.KW) / stride + 1;
-    p.nchunk = c->cw.nchunk; p.tail = c->cw.tail; p.lrelu = leaky;
+    p.nchunk = c->cw.nchunk; p.tail = c->cw.tail; p.lrelu = leaky; p.cin_real = c->cw.cin;
     p.scratch = c->scratch; p.scratch_floats = KSPLIT_FLOATS;
     // the (7 x 1) distance convolution on >= 256 x 256 images: the kernel pivlfn_forward uses for it in the fp32 mode
     if (c->cw.wpk_c && !res && !leaky && stride == 1 && pad_y == 3 && pad_x == 0 && (long)H * W >= 256 * 256 && p.cout_store % 4 == 0 &&
@@ -652,7 +652,7 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
     p.KH = cw.KH; p.KW = cw.KW; p.S = S; p.padY = padY; p.padX = padX;
     p.Ho = Ho;
     p.Wo = Wo;
-    p.nchunk = cw.nchunk; p.tail = cw.tail; p.lrelu = lrelu;
+    p.nchunk = cw.nchunk; p.tail = cw.tail; p.lrelu = lrelu; p.cin_real = cw.cin;
     p.scratch = (t_side && st == t_side) ? nullptr : t_scratch;      // one scratch area: the side stream never splits
     p.scratch_floats = KSPLIT_FLOATS * B;
     return launch_conv(p, st);

@@ -48,6 +48,7 @@ def run(conv, x_nchw, stride, pad, leaky, dev, res=None, x_lanes=None):
 CASES = [
     # cout, cin, kh, kw, stride, pad, H, W, B  -- one per kernel family of SURVEY.md appendix B
     (32, 3, 7, 7, 1, (3, 3), 40, 72, 2),          # NetC.conv1
+    (32, 3, 7, 7, 1, (3, 3), 261, 530, 2),        # NetC.conv1 at >= 512 tiles of 8 x 32 outputs per image: taps packed into K, ragged edges
     (32, 32, 3, 3, 2, (1, 1), 64, 96, 1),         # NetC stride-2
     (64, 32, 3, 3, 2, (1, 1), 33, 47, 1),         # odd sizes
     (32, 32, 3, 3, 2, (1, 1), 262, 530, 1),       # NetC.conv2.0 at >= 256 tiles of 8 x 16 outputs: the whole-line stride-2 kernel, ragged edges
