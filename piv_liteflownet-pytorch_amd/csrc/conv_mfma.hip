@@ -814,14 +814,17 @@ __global__ __launch_bounds__(256) void conv_s2c32_kernel(const ConvParams p)
         }                                                                                         \
     } while (0)
 
+#ifndef S2_ABL_CT
+#define S2_ABL_CT 0               // timing-only ablations (tools/ab_variant.sh): 1 no MFMAs, 2 no patch loads after the first, 4 no stores, 8 no LDS commit, 16 no barriers
+#endif
     S2_LOAD(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();          // the previous tile's operand reads are done (first pass: the weights are written)
+        if (!(S2_ABL_CT & 16)) __syncthreads();          // the previous tile's operand reads are done (first pass: the weights are written)
 #pragma unroll
         for (int i = 0; i < S2_PMAX; ++i)
-            if (pyx[i] != 0xffffu) *reinterpret_cast<f32x4 *>(patch + (pix0 + 32 * i) * S2_PIXP + 4 * q) = pr[i];
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) S2_LOAD(tile + gridDim.x);
+            if (pyx[i] != 0xffffu && (!(S2_ABL_CT & 8) || tile == (int)blockIdx.x)) *reinterpret_cast<f32x4 *>(patch + (pix0 + 32 * i) * S2_PIXP + 4 * q) = pr[i];
+        if (!(S2_ABL_CT & 16)) __syncthreads();
+        if (tile + (int)gridDim.x < ntiles && !(S2_ABL_CT & 2)) S2_LOAD(tile + gridDim.x);
         f32x16 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -830,7 +833,11 @@ __global__ __launch_bounds__(256) void conv_s2c32_kernel(const ConvParams p)
         // 36 steps (group c, tap): one 16-byte read of either operand feeds four MFMAs.  The reads run S2_D steps ahead of their
         // MFMAs, pinned by scheduling fences: with one wave per SIMD nothing else covers an LDS round trip (left to the compiler the
         // reads sit right in front of their use).  Measured: the same 120 us on 32 -> 32 at 1024^2 either way -- a tile takes
-        // 17.8 k cycles for 9.2 k of matrix work; what the other half is has not been taken apart yet.
+        // 17.8 k cycles for 9.2 k of matrix work.  Compile-time ablations (S2_ABL_CT, tools/ab_variant.sh; us per launch): whole
+        // 121.7, without the MFMAs 70.9, without the next patch's loads 96.9, without the stores 109.0, without the LDS commit
+        // 116.8, without the barriers 122.1, with none of the first four 22.5 -- the pieces ADD (51 + 25 + 13 + 5 + 22): one wave per
+        // SIMD runs them in order and nothing else is there to overlap them.  Two workgroups per CU need the weights out of LDS
+        // (patch 80.8 KB): from global memory that was 291 us (header), in registers 144 + 72 staging registers do not fit 256.
         constexpr int S2_D = 3;
         f32x4 av[36], bv[36][NT];
 #define S2_READ(S)                                                                                \
@@ -849,7 +856,10 @@ __global__ __launch_bounds__(256) void conv_s2c32_kernel(const ConvParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[s_][n][j], av[s_][j], acc[n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) {
+                    if (S2_ABL_CT & 1) acc[n][(s_ + j) & 15] += bv[s_][n][j] * av[s_][j];
+                    else acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[s_][n][j], av[s_][j], acc[n], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef S2_READ
@@ -859,7 +869,7 @@ __global__ __launch_bounds__(256) void conv_s2c32_kernel(const ConvParams p)
         t_ /= tiles_x;
         const int b = t_ / tiles_y;
         const int oy = (t_ - b * tiles_y) * 8 + wave * 2 + prow, ox = tx * 16 + pcol;
-        if (oy < p.Ho && ox < p.Wo) {
+        if (oy < p.Ho && ox < p.Wo && (!(S2_ABL_CT & 4) || acc[0][0] == 12345.f)) {
             float *orow = p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.out_stride + n0;
 #pragma unroll
             for (int n = 0; n < NT; ++n)

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "piv_liteflownet-pytorch_amd"))
 from pivlfn import _lib  # noqa: E402
 
-PATH = os.path.join(ROOT, "tools", "libpivlfn_tools.so")
+PATH = os.environ.get("PIVLFN_TOOLS_LIB") or os.path.join(ROOT, "tools", "libpivlfn_tools.so")       # the override: variant builds of tools/ab_variant.sh
 _tools = None
 
 
