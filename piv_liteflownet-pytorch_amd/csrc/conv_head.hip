@@ -402,7 +402,7 @@ int launch_conv_col7(const float *x, int x_stride, const float *wf, const float 
     PIV_REQUIRE(x_stride % 4 == 0 && out_stride % 4 == 0 && cout_store % 4 == 0 && cout_store <= 64 && cout_store <= out_stride, "conv_col7: bad strides");
     // the 49-channel path leaves channel 48's value in all four lane groups of block 3 and relies on only lane group 0 being stored
     PIV_REQUIRE(!single48 || cout_store == 52, "conv_col7: the 49-channel layer stores 52 lanes (got %d)", cout_store);
-    PIV_REQUIRE((long)H * W * x_stride * 4 < (1L << 31), "conv_col7: image exceeds 2 GiB");
+    PIV_REQUIRE((long)H * W * std::max(x_stride, out_stride) * 4 < (1L << 31), "conv_col7: image exceeds 2 GiB (32-bit buffer offsets for the loads and the stores)");
     constexpr int TH = 16;
     hipLaunchKernelGGL((conv_col7_kernel<TH>), dim3(cdiv(cdiv(W, 16) * cdiv(H, TH) * B, 4)), dim3(256), 0, st, x, x_stride, wf, bias, out, out_stride, cout_store, single48, B, H, W);
     PIV_CHECK_HIP(hipGetLastError());
@@ -565,7 +565,7 @@ int launch_conv_row7(const float *x, int x_stride, const float *wf, const float 
 {
     PIV_REQUIRE(x && wf && wf12 && bias && out && B > 0 && H > 0 && W > 0, "conv_row7: bad arguments");
     PIV_REQUIRE(x_stride % 4 == 0 && x_stride >= 52 && out_stride % 4 == 0 && out_stride >= 52, "conv_row7: 52 stored lanes in and out (strides %d, %d)", x_stride, out_stride);
-    PIV_REQUIRE((long)H * W * x_stride * 4 < (1L << 31), "conv_row7: image exceeds 2 GiB");
+    PIV_REQUIRE((long)H * W * std::max(x_stride, out_stride) * 4 < (1L << 31), "conv_row7: image exceeds 2 GiB (32-bit buffer offsets for the loads and the stores)");
     constexpr int TW = 16;
     hipLaunchKernelGGL((conv_row7_kernel<TW>), dim3(cdiv(cdiv(W, TW) * cdiv(H, 16) * B, 4)), dim3(256), 0, st, x, x_stride, wf, wf12, bias, out, out_stride, B, H, W,
                        reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5)));   // tools build only

@@ -488,10 +488,10 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
     p.scratch = c->scratch; p.scratch_floats = KSPLIT_FLOATS;
     // the (7 x 1) distance convolution on >= 256 x 256 images: the kernel pivlfn_forward uses for it in the fp32 mode
     if (c->cw.wpk_c && !res && !leaky && stride == 1 && pad_y == 3 && pad_x == 0 && (long)H * W >= 256 * 256 && p.cout_store % 4 == 0 &&
-        (long)H * W * x_stride * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
+        (long)H * W * std::max(x_stride, y_stride) * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
         return launch_conv_col7(x, x_stride, c->cw.wpk_c, c->cw.bias, y, y_stride, p.cout_store, c->cw.cout == 49, B, H, W, st);
     if (c->cw.wpk_r && !res && !leaky && stride == 1 && pad_y == 0 && pad_x == 3 && (long)H * W >= 256 * 256 && x_stride >= 52 && y_stride >= 52 &&
-        (long)H * W * x_stride * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
+        (long)H * W * std::max(x_stride, y_stride) * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
         return launch_conv_row7(x, x_stride, c->cw.wpk_r, c->cw.wpk_r12, c->cw.bias, y, y_stride, B, H, W, st);
     return launch_conv(p, st);
 }
@@ -613,11 +613,11 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
     // fp32 mode: the (7 x 1) distance convolution of levels 1 and 2 on its streaming matrix-core kernel (per image: >= 256 x 256)
     if (t_precision == 0 && !res && cw.wpk_c && cw.KH == 7 && cw.KW == 1 && S == 1 && padY == 3 && padX == 0 && !lrelu &&
         segs.size() == 1 && segs.begin()->cload == 32 && (long)Ho * Wo >= 256 * 256 && cout_store % 4 == 0 &&
-        (long)H * W * segs.begin()->stride * 4 < (1L << 31) && cw.cout_pad <= 64)
+        (long)H * W * std::max(segs.begin()->stride, out_stride) * 4 < (1L << 31) && cw.cout_pad <= 64)
         return launch_conv_col7(segs.begin()->ptr, segs.begin()->stride, cw.wpk_c, cw.bias, out, out_stride, cout_store, cw.cout == 49, B, H, W, st);
     if (t_precision == 0 && !res && cw.wpk_r && cw.KH == 1 && cw.KW == 7 && S == 1 && padY == 0 && padX == 3 && !lrelu &&
         segs.size() == 1 && segs.begin()->cload == 52 && segs.begin()->stride >= 52 && out_stride >= 52 && cout_store == 52 &&
-        (long)Ho * Wo >= 256 * 256 && (long)H * W * segs.begin()->stride * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
+        (long)Ho * Wo >= 256 * 256 && (long)H * W * std::max(segs.begin()->stride, out_stride) * 4 < (1L << 31) && !(PIV_KNOB(1) & 65536))
         return launch_conv_row7(segs.begin()->ptr, segs.begin()->stride, cw.wpk_r, cw.wpk_r12, cw.bias, out, out_stride, B, H, W, st);
     // fp32 mode: the 3 x 3 / stride 1 layers by Winograd F(2x2, 3x3) on the fp32 matrix instruction (conv_wino.hip) from a
     // 64 x 64 grid per image up (a 32 x 32 grid is 32 workgroups with the whole K loop each: the split-K direct kernel is faster);
