@@ -326,13 +326,9 @@ __global__ __launch_bounds__(256, 2) void conv_col7_kernel(const float *__restri
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * img * out_stride, 0,
                                                                            (unsigned)(((img - 1) * out_stride + cout_store) * sizeof(float)), 0x00020000);
     const bool chin = xin && ch < cout_store;
-    f32x4h acc[TH];
-    {
-        f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
-        if (vec48 && kq != 0) b4 = f32x4h{0.f, 0.f, 0.f, 0.f};      // the vector path adds its four lane groups at the end: the bias once
-#pragma unroll
-        for (int i = 0; i < TH; ++i) acc[i] = b4;
-    }
+    f32x4h acc[TH];           // acc[i] is live from input row i (its first tap) to input row i + 6 (its store): seven or eight at a time
+    f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
+    if (vec48 && kq != 0) b4 = f32x4h{0.f, 0.f, 0.f, 0.f};      // the vector path adds its four lane groups at the end: the bias once
     f32x4h Bq[NR][2];
 #define COL_LOAD(RI)                                                                              \
     do {                                                                                          \
@@ -346,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_col7_kernel(const float *__restri
 #pragma unroll
     for (int ri = 0; ri < NR; ++ri) {
         if (ri + AHEAD < NR) COL_LOAD(ri + AHEAD);
+        if (ri < TH) acc[ri] = b4;
         __builtin_amdgcn_sched_barrier(0);
         if (vec48) {
             // 49 output channels = three 16-channel blocks + ONE channel: a fourth MFMA block would spend 15 of its 16 rows on
@@ -463,13 +460,9 @@ __global__ __launch_bounds__(256, 2) void conv_row7_kernel(const float *__restri
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * img * out_stride, 0,
                                                                            (unsigned)(((img - 1) * out_stride + 52) * sizeof(float)), 0x00020000);
     const bool chin = rin && ch < 52;
-    f32x4h acc[TW];
-    {
-        f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
-        if (blk == 3 && kq != 0) b4 = f32x4h{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < TW; ++i) acc[i] = b4;
-    }
+    f32x4h acc[TW];           // acc[i] is live from input column i to input column i + 6
+    f32x4h b4 = *reinterpret_cast<const f32x4h *>(bias + ch);
+    if (blk == 3 && kq != 0) b4 = f32x4h{0.f, 0.f, 0.f, 0.f};
     f32x4h Bq[NC][3];
     float B12[NC];
     // out-of-range columns and rows read zeros (offsets past the descriptor); channel 48 is real in lane group kq = 0 only
@@ -493,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void conv_row7_kernel(const float *__restri
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci) {
         if (ci + AHEAD < NC) ROW_LOAD(ci + AHEAD);
+        if (ci < TW) acc[ci] = b4;
         __builtin_amdgcn_sched_barrier(0);
         if (blk == 3) {
             // channel 48 on the vector unit: the fragment registers hold its weights (replicated over the slots at pack time); every
