@@ -35,7 +35,7 @@ typedef struct {
 } pivlfn_tensor;
 
 const char *pivlfn_last_error(void);
-/* ABI version.  2 (round 4): + pivlfn_warp_corr_nhwc_timed, pivlfn_conv2d_nhwc_wino4; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
+/* ABI version.  2 (round 4): + pivlfn_warp_corr_nhwc_timed, pivlfn_conv2d_nhwc_wino4, pivlfn_conv_create_cat, pivlfn_conv2d_nhwc_cat; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
  * (added in round 3 without a bump).  No entry point of version 1 changed its signature or meaning. */
 int         pivlfn_abi_version(void);
 
@@ -175,6 +175,17 @@ int pivlfn_conv2d_nhwc_wino(const pivlfn_conv *conv, const float *x, int x_strid
  * and kept as an entry point only: pivlfn_forward does not use it (0.98x of F(2x2) on 128->128 at 1024 x 1024, slower below). */
 int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                              int B, int H, int W, int leaky, void *stream);
+
+/* One Conv2d (odd k, stride 1, "same" padding, + bias, optional LeakyReLU(0.1)) over the channel concatenation of 1-3 sources --
+ * torch.cat + Conv2d of the front layers of Matching / Subpixel / Regularization (src/models.py:171-187, 209-217, 280) -- through
+ * the dispatch of PIVLFN_PRECISION_F32: the multi-source staging of the direct and the Winograd kernel, for per-layer checks.
+ * weight is OIHW over the concatenated channels; channels[i] = real channels of source i; x[i] is [B,H,W,x_stride[i]] with
+ * x_stride[i] a multiple of 4 and >= channels[i] rounded up to 4 (padding lanes zero); only the last source may have a channel
+ * count that is 4 (mod 8) after rounding. */
+int pivlfn_conv_create_cat(const float *weight, const float *bias, int cout, int nsrc, const int *channels, int kh, int kw,
+                           pivlfn_conv **out);
+int pivlfn_conv2d_nhwc_cat(const pivlfn_conv *conv, int nsrc, const float *const *x, const int *x_stride, float *y, int y_stride,
+                           int B, int H, int W, int leaky, void *stream);
 
 /* The 32 -> 2 channel k x k flow head (conv_M.6 / conv_S.6) on its dedicated kernel: x [B,H,W,32], res4/out4 [B,H,W,4]. */
 int pivlfn_conv_head_nhwc(const pivlfn_conv *conv, const float *x, const float *res4, float *out4, int B, int H, int W,

@@ -55,6 +55,9 @@ int net_set_precision(pivlfn_net *net, int precision);
 int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride,
                    int B, int H, int W, int stride, int pad_y, int pad_x, int leaky, int terms, hipStream_t st);
 int conv_head_forward(const pivlfn_conv *c, const float *x, const float *res4, float *out4, int B, int H, int W, hipStream_t st);
+int conv_create_cat(const float *weight, const float *bias, int cout, int nsrc, const int *channels, int kh, int kw, pivlfn_conv **out);
+int conv_forward_cat(const pivlfn_conv *c, int nsrc, const float *const *x, const int *x_stride, float *y, int y_stride,
+                     int B, int H, int W, int leaky, hipStream_t st);
 int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, int B, int H, int W, int leaky,
                    hipStream_t st, int tile);
 
@@ -172,6 +175,17 @@ int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stri
                              int B, int H, int W, int leaky, void *stream)
 {
     return conv_forward_w(conv, x, x_stride, y, y_stride, B, H, W, leaky, (hipStream_t)stream, 4);
+}
+
+int pivlfn_conv_create_cat(const float *weight, const float *bias, int cout, int nsrc, const int *channels, int kh, int kw, pivlfn_conv **out)
+{
+    return conv_create_cat(weight, bias, cout, nsrc, channels, kh, kw, out);
+}
+
+int pivlfn_conv2d_nhwc_cat(const pivlfn_conv *conv, int nsrc, const float *const *x, const int *x_stride, float *y, int y_stride,
+                           int B, int H, int W, int leaky, void *stream)
+{
+    return conv_forward_cat(conv, nsrc, x, x_stride, y, y_stride, B, H, W, leaky, (hipStream_t)stream);
 }
 
 int pivlfn_set_precision(pivlfn_net *net, int precision) { return net_set_precision(net, precision); }

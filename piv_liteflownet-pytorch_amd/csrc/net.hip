@@ -60,6 +60,8 @@ struct pivlfn_net;
 struct pivlfn_conv {
     pivlfn::ConvW cw;
     int cin = 0;
+    int nsrc = 1;              // sources of the layer (pivlfn_conv_create_cat: a convolution over a channel concatenation)
+    int src_real[3] = {0, 0, 0};
     float *scratch = nullptr;  // split-K scratch (KSPLIT_FLOATS), allocated by conv_create
     float *head = nullptr;     // set when the layer is a 32->2 kxk flow head
     float hb[2] = {0.f, 0.f};
@@ -496,6 +498,38 @@ int conv_forward(const pivlfn_conv *c, const float *x, int x_stride, float *y, i
     return launch_conv(p, st);
 }
 
+// One Conv2d over the channel concatenation of up to three sources (torch.cat + Conv2d, src/models.py:165-187, 209-217, 280: the
+// front layers of Matching / Subpixel / Regularization), through the same dispatch as pivlfn_forward's fp32 mode: multi-source
+// staging of the direct and the Winograd kernel for per-layer checks.
+int conv_create_cat(const float *weight, const float *bias, int cout, int nsrc, const int *channels, int kh, int kw, pivlfn_conv **out)
+{
+    PIV_REQUIRE(weight && bias && out && channels && cout > 0 && nsrc >= 1 && nsrc <= 3 && kh > 0 && kw > 0, "conv_create_cat: bad arguments");
+    int cin = 0;
+    std::vector<SegDef> segs;
+    for (int i = 0; i < nsrc; ++i) {
+        PIV_REQUIRE(channels[i] > 0, "conv_create_cat: source %d has %d channels", i, channels[i]);
+        segs.push_back(SegDef{channels[i], rup(channels[i], 4)});
+        cin += channels[i];
+    }
+    pivlfn_tensor t[2];
+    t[0].name = "c.weight"; t[0].data = weight; t[0].ndim = 4;
+    t[0].shape[0] = cout; t[0].shape[1] = cin; t[0].shape[2] = kh; t[0].shape[3] = kw;
+    t[1].name = "c.bias"; t[1].data = bias; t[1].ndim = 1;
+    t[1].shape[0] = cout; t[1].shape[1] = t[1].shape[2] = t[1].shape[3] = 0;
+    TMap m;
+    m["c.weight"] = &t[0];
+    m["c.bias"] = &t[1];
+    pivlfn_conv *c = new pivlfn_conv();
+    c->owner = new pivlfn_net();
+    c->cin = cin;
+    c->nsrc = nsrc;
+    for (int i = 0; i < nsrc; ++i) c->src_real[i] = channels[i];
+    const int rc = pack_conv(c->owner, m, "c", cout, cin, kh, kw, segs, &c->cw);
+    if (rc) { net_destroy(c->owner); delete c; return rc; }
+    *out = c;
+    return PIVLFN_OK;
+}
+
 int conv_head_forward(const pivlfn_conv *c, const float *x, const float *res4, float *out4, int B, int H, int W, hipStream_t st)
 {
     PIV_REQUIRE(c && c->head, "conv_head: the layer is not a 32->2 kxk flow head");
@@ -727,6 +761,28 @@ int conv_forward_x(const pivlfn_conv *c, const float *x, int x_stride, float *y,
 }
 
 // Standalone 3 x 3 / stride 1 / pad 1 layer on the Winograd kernels (tests, tools): fp32 in, fp32 out.  tile = 2: F(2x2, 3x3), 4: F(4x4, 3x3).
+int conv_forward_cat(const pivlfn_conv *c, int nsrc, const float *const *x, const int *x_stride, float *y, int y_stride,
+                     int B, int H, int W, int leaky, hipStream_t st)
+{
+    PIV_REQUIRE(c && x && x_stride && y && nsrc == c->nsrc, "conv2d_cat: the layer was created for %d sources", c ? c->nsrc : 0);
+    PIV_REQUIRE(B > 0 && H > 0 && W > 0 && c->cw.KH % 2 == 1 && c->cw.KW % 2 == 1, "conv2d_cat: bad shape");
+    PIV_REQUIRE(y_stride % 4 == 0 && y_stride >= c->cw.cout, "conv2d_cat: y_stride=%d must be a multiple of 4 and >= cout=%d", y_stride, c->cw.cout);
+    ConvSeg sg[3];
+    for (int i = 0; i < nsrc; ++i) {
+        PIV_REQUIRE(x[i] && x_stride[i] % 4 == 0 && x_stride[i] >= rup(c->src_real[i], 4), "conv2d_cat: source %d: stride %d for %d channels", i, x_stride[i], c->src_real[i]);
+        sg[i] = ConvSeg{x[i], rup(c->src_real[i], 4), x_stride[i]};
+    }
+    t_precision = 0;
+    t_side = nullptr;
+    t_scratch = nullptr;          // never split: the handle has no per-batch scratch
+    const int cs = std::min(rup(c->cw.cout, 4), y_stride);
+    switch (nsrc) {
+        case 1: return conv(c->cw, {sg[0]}, y, y_stride, cs, nullptr, 0, leaky, B, H, W, 1, c->cw.KH / 2, c->cw.KW / 2, st, 0, 0);
+        case 2: return conv(c->cw, {sg[0], sg[1]}, y, y_stride, cs, nullptr, 0, leaky, B, H, W, 1, c->cw.KH / 2, c->cw.KW / 2, st, 0, 0);
+        default: return conv(c->cw, {sg[0], sg[1], sg[2]}, y, y_stride, cs, nullptr, 0, leaky, B, H, W, 1, c->cw.KH / 2, c->cw.KW / 2, st, 0, 0);
+    }
+}
+
 int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, int B, int H, int W, int leaky,
                    hipStream_t st, int tile)
 {

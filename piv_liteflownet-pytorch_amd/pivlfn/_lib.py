@@ -24,6 +24,8 @@ SIGNATURES = {
     "pivlfn_conv2d_nhwc_f16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "pivlfn_conv2d_nhwc_split": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 8 + [ctypes.c_void_p]),
     "pivlfn_conv2d_nhwc_wino": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "pivlfn_conv_create_cat": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "pivlfn_conv2d_nhwc_cat": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "pivlfn_conv2d_nhwc_wino4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "pivlfn_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pivlfn_backwarp": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

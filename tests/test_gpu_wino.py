@@ -155,3 +155,55 @@ def test_default_mode_is_fp32_with_winograd(dev):
     d = (fw - fd).abs().max().item()
     print(f"piv 256x256: max |flow(fp32, Winograd) - flow(fp32_direct)| = {d:.2e} px at max |flow| {fd.abs().max().item():.2f}")
     assert d < 1e-4 * max(1.0, fd.abs().max().item())
+
+
+# ---- several sources: torch.cat + Conv2d through the fp32 dispatch (pivlfn_conv2d_nhwc_cat) -------------------------------------------
+# The front layers of Matching / Subpixel / Regularization read a channel concatenation (src/models.py:171-187, 209-217, 280).  The
+# kernels stage it source by source: per-source descriptors, a source switch inside the staging loop, a 4-lane tail that only the
+# last source may have.  Sizes: below 64 x 64 the direct kernel runs, from there up the Winograd kernel, at 256 x 272 with every CU
+# holding two workgroups.
+CAT_CASES = [
+    # cout, channels per source, lanes per source (None = channels rounded up to 4), H, W, B
+    (128, (64, 64, 2), (64, 72, 4), 32, 40, 1),            # conv_S.0 of levels 1-3 below the Winograd bound: direct kernel, a wider second source
+    (128, (64, 64, 2), None, 80, 96, 1),                   # conv_S.0 on the Winograd kernel: three sources, 4-lane tail in the last
+    (128, (128, 3), (128, 4), 72, 64, 2),                  # conv_R.0 (moduleFeat + 3 flow channels), batch 2
+    (128, (96, 96, 2), None, 67, 83, 1),                   # conv_S.0 of level 4 (C = 96): sources that are not multiples of 64, ragged size
+    (128, (64, 64, 2), None, 256, 272, 1),                 # full occupancy
+    (128, (128, 3), (136, 4), 261, 280, 1),                # full occupancy, ragged, the first source inside a wider tensor
+]
+
+
+@pytest.mark.parametrize("case", CAT_CASES)
+def test_concatenated_sources_match_float64_conv(case, dev):
+    import ctypes
+    co, chans, lanes, H, W, B = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(co + sum(chans) + H)
+    cin = sum(chans)
+    w = (torch.randn(co, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).contiguous()
+    b = (torch.randn(co, generator=g) * 0.1).contiguous()
+    srcs = [torch.randn(B, c, H, W, generator=g) for c in chans]
+    want = F.leaky_relu(F.conv2d(torch.cat(srcs, 1).double(), w.double(), b.double(), padding=1), 0.1)
+    h = ctypes.c_void_p()
+    ch = (ctypes.c_int * len(chans))(*chans)
+    _lib.check(lib.pivlfn_conv_create_cat(w.data_ptr(), b.data_ptr(), co, len(chans), ch, 3, 3, ctypes.byref(h)), "conv_create_cat")
+    try:
+        lanes = lanes or tuple(-(-c // 4) * 4 for c in chans)
+        dev_srcs = []
+        for s_, c, l in zip(srcs, chans, lanes):
+            t = torch.zeros(B, H, W, l)
+            t[..., :c] = s_.permute(0, 2, 3, 1)
+            if l > -(-c // 4) * 4:
+                t[..., -(-c // 4) * 4:] = float("nan")          # lanes beyond the source's own are never read
+            dev_srcs.append(t.to(dev))
+        ptrs = (ctypes.c_void_p * len(chans))(*[t.data_ptr() for t in dev_srcs])
+        strides = (ctypes.c_int * len(chans))(*lanes)
+        y = torch.full((B, H, W, co), float("nan"), device=dev)
+        _lib.check(lib.pivlfn_conv2d_nhwc_cat(h, len(chans), ptrs, strides, y.data_ptr(), co, B, H, W, 1,
+                                              torch.cuda.current_stream(dev).cuda_stream), "conv2d_cat")
+        got = y.cpu().permute(0, 3, 1, 2).double()
+        err = (got - want).abs().max().item()
+        print(f"cat {chans} -> {co} at {H}x{W} B={B}: max abs err {err:.2e} at max |out| {want.abs().max().item():.2f}")
+        assert err < 1e-5 * max(1.0, want.abs().max().item()), (case, err)
+    finally:
+        lib.pivlfn_conv_destroy(h)
