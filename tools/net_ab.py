@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--knob", type=int, default=1, help="which pivlfn_tune knob the masks go to (1 = variant bits, 2 = warp+correlation debug mask)")
+    ap.add_argument("--profile-level", type=int, default=0, help="also time this level's warp+correlation launch with dispatch events (pivlfn_profile_enable)")
     a = ap.parse_args()
     lib = _toolslib.load()
     _lib._lib = lib
@@ -34,20 +36,27 @@ def main():
     ref = None
     for rnd in range(a.rounds):
         for m in masks:
-            lib.pivlfn_tune(1, m)
+            lib.pivlfn_tune(a.knob, m)
             for _ in range(3):
                 out = net(i1, i2)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if a.profile_level:
+                net.profile_enable(a.profile_level)
             e0.record()
             for _ in range(a.steps):
                 out = net(i1, i2)
             e1.record()
             torch.cuda.synchronize()
+            extra = ""
+            if a.profile_level:
+                k_ms, _, k_n = net.profile_read()
+                net.profile_enable(0)
+                extra = f"   level-{a.profile_level} warp+correlation {1e3 * k_ms / max(1, k_n):6.2f} us (n={k_n})"
             if ref is None:
                 ref = out.clone()
-            print(f"round {rnd} mask {m:5d}: {e0.elapsed_time(e1) / a.steps:8.3f} ms / forward   max|diff vs first| {(out - ref).abs().max().item():.2e}", flush=True)
-    lib.pivlfn_tune(1, 0)
+            print(f"round {rnd} mask {m:5d}: {e0.elapsed_time(e1) / a.steps:8.3f} ms / forward   max|diff vs first| {(out - ref).abs().max().item():.2e}" + extra, flush=True)
+    lib.pivlfn_tune(a.knob, 0)
 
 
 if __name__ == "__main__":
