@@ -116,6 +116,16 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);
+// NetC.conv1 with the two 1 x 1 layers that read its output at level 1 -- NetC_ext (32 -> 64, both frames) and Regularization's
+// moduleFeat (32 -> 128, first frame) -- computed from the activated accumulators in the same kernel (conv_mfma.hip).
+struct Conv1Fuse {
+    const float *w11;   // [6 blocks: 2 of NetC_ext, 4 of moduleFeat][4 groups][64 lanes][4]: W[32 blk + (lane & 31)][8 g + 4 (lane >> 5) + e]
+    const float *b11;   // [64 + 128]
+    float *out_ext;     // [images][H][W][64]
+    float *out_feat;    // [first B_feat images][H][W][128]
+    int B_feat;
+};
+int launch_conv1_fused(const ConvParams &p, const Conv1Fuse &f, hipStream_t st);     // -1: the layer / size is not covered
 int launch_touch(const float *p, size_t floats, float *sink, hipStream_t st);     // read-only prefetch pass (ops.hip)
 int launch_splitk_reduce(const ConvParams &p, int nz, hipStream_t st);     // second pass of a split-K layer (also used by conv_split.hip)
 

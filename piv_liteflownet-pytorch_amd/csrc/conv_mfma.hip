@@ -624,9 +624,17 @@ static int launch_conv_k1(const ConvParams &p, hipStream_t st)
 // 6.5 KB: three workgroups per CU.  K order: rows, then slot pairs (conv_k1: taps, then channel pairs).
 constexpr int C3_PW = 38, C3_PITCH = 116, C3_PH = 14;         // patch of an 8 x 32 tile, floats per patch row (38 x 3 + the pad slot)
 
-__global__ __launch_bounds__(256, 3) void conv_c3k7_kernel(const ConvParams p)
+// FUSE: the level-1 1 x 1 layers on top (Conv1Fuse): the accumulator layout of the 32 x 32 x 2 instruction is already its B-operand
+// layout -- lane (pixel, hh) holds channels 8 g + 4 hh + e in register 4 g + e, and k-slot hh of the MFMA (g, e) wants exactly that
+// channel -- so the activated accumulators feed the next MFMAs without a transpose: 16 MFMAs per 32 output channels.
+template <bool FUSE>
+__global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const ConvParams p, const Conv1Fuse f)
 {
     __shared__ __attribute__((aligned(16))) float patch[C3_PH * C3_PITCH + 4];
+    __shared__ __attribute__((aligned(16))) float w11s[FUSE ? 6 * 4 * 64 * 4 : 4];
+    if (FUSE) {
+        for (int i = threadIdx.x; i < 6 * 4 * 64; i += 256) reinterpret_cast<f32x4 *>(w11s)[i] = reinterpret_cast<const f32x4 *>(f.w11)[i];
+    }
     constexpr int TH = 8;
     const int tiles_x = (p.Wo + 31) >> 5, tiles_y = (p.Ho + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * p.B;
@@ -709,17 +717,54 @@ __global__ __launch_bounds__(256, 3) void conv_c3k7_kernel(const ConvParams p)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int oy = y0 + wave * 2 + m;
-            if (oy >= p.Ho || ox >= p.Wo) continue;
-            float *orow = p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.out_stride;
+            const bool ok = oy < p.Ho && ox < p.Wo;
+            float *orow = p.out + ((size_t)(b * p.Ho + (ok ? oy : 0)) * p.Wo + (ok ? ox : 0)) * p.out_stride;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (8 * g + 4 * hh >= p.cout_store) continue;
                 f32x4 v = {acc[m][4 * g + 0], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
                 v += bias4[g];
                 if (p.lrelu) {
                     v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
                 }
-                *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * hh) = v;
+                if (ok && 8 * g + 4 * hh < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * hh) = v;
+                if (FUSE) { acc[m][4 * g + 0] = v[0]; acc[m][4 * g + 1] = v[1]; acc[m][4 * g + 2] = v[2]; acc[m][4 * g + 3] = v[3]; }
+            }
+        }
+        if (FUSE) {
+            // blocks 0, 1: NetC_ext (64 channels, every image); blocks 2..5: moduleFeat (128 channels, the first B_feat images)
+            const int nblk = b < f.B_feat ? 6 : 2;
+#pragma unroll 1
+            for (int blk = 0; blk < nblk; ++blk) {
+                f32x16 a2[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a2[m][r] = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 wv = reinterpret_cast<const f32x4 *>(w11s)[(blk * 4 + g) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) a2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e], acc[m][4 * g + e], a2[m], 0, 0, 0);
+                }
+                const bool ext = blk < 2;
+                const int cb = ext ? 32 * blk : 32 * (blk - 2), cs = ext ? 64 : 128;
+                const float *bsrc = f.b11 + (ext ? 0 : 64) + cb + 4 * hh;
+                float *obase = ext ? f.out_ext : f.out_feat;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = y0 + wave * 2 + m;
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                    float *orow = obase + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * cs + cb + 4 * hh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {a2[m][4 * g + 0], a2[m][4 * g + 1], a2[m][4 * g + 2], a2[m][4 * g + 3]};
+                        v += *reinterpret_cast<const f32x4 *>(bsrc + 8 * g);
+                        v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
+                        *reinterpret_cast<f32x4 *>(orow + 8 * g) = v;
+                    }
+                }
             }
         }
     }
@@ -736,7 +781,22 @@ static int launch_conv_c3k7(const ConvParams &p, hipStream_t st)
     if ((long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) < 512) return -1;             // per image: never a function of the batch
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    hipLaunchKernelGGL(conv_c3k7_kernel, dim3((unsigned)std::min<long>(tiles, 3L * cus)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_c3k7_kernel<false>), dim3((unsigned)std::min<long>(tiles, 3L * cus)), dim3(256), 0, st, p, Conv1Fuse{});
+    PIV_CHECK_HIP(hipGetLastError());
+    return PIVLFN_OK;
+}
+
+// conv1 + NetC_ext + moduleFeat of level 1 in one launch (same applicability as launch_conv_c3k7; cout_store 32, LeakyReLU on)
+int launch_conv1_fused(const ConvParams &p, const Conv1Fuse &f, hipStream_t st)
+{
+    if (p.KH != 7 || p.KW != 7 || p.S != 1 || p.padY != 3 || p.padX != 3 || p.nseg != 1 || p.seg[0].cload != 4 || p.nchunk != 1 || !p.tail ||
+        p.res || p.cout_pad != 32 || p.cin_real != 3 || p.cout_store != 32 || !p.lrelu || !f.w11 || !f.b11 || !f.out_ext || !f.out_feat)
+        return -1;
+    if ((long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) < 512) return -1;             // per image: never a function of the batch
+    const long tiles = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL((conv_c3k7_kernel<true>), dim3((unsigned)std::min<long>(tiles, 2L * cus)), dim3(256), 0, st, p, f);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }

@@ -82,6 +82,7 @@ struct pivlfn_net {
     std::vector<void *> allocs;
     // side stream for the flow-independent 1x1 convs (NetC_ext, moduleFeat): they overlap the latency-bound coarse levels
     hipStream_t side = nullptr;
+    float *fuse1_w = nullptr, *fuse1_b = nullptr;      // level 1: NetC_ext + moduleFeat as 1 x 1 layers inside NetC.conv1's kernel (Conv1Fuse)
     hipEvent_t ev_fork[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // measurement hooks
     int prof_level = 0;
@@ -416,6 +417,27 @@ int net_create(const pivlfn_tensor *tensors, int n, float starting_scale, int lo
         TRY(upload(net, std::vector<float>(wy->data, wy->data + kk), &lw.wy));
         lw.bx = bx->data[0];
         lw.by = by->data[0];
+    }
+    if (lowest == 1) {      // the two 1 x 1 layers that read NetC.conv1's output at level 1, in the fragment order of Conv1Fuse
+        int j = -1;
+        if (j < 0) j += n_ext;                       // NetC_ext index of level 1 (python negative index, as above)
+        const pivlfn_tensor *we = find(m, "NetC_ext." + std::to_string(j) + ".conv_ext.0.weight", 64, 32, 1, 1, 4);
+        const pivlfn_tensor *be = find(m, "NetC_ext." + std::to_string(j) + ".conv_ext.0.bias", 64, 0, 0, 0, 1);
+        const pivlfn_tensor *wf = find(m, "NetE_R." + std::to_string(1 - lowest) + ".moduleFeat.0.weight", 128, 32, 1, 1, 4);
+        const pivlfn_tensor *bfe = find(m, "NetE_R." + std::to_string(1 - lowest) + ".moduleFeat.0.bias", 128, 0, 0, 0, 1);
+        if (!we || !be || !wf || !bfe) { net_destroy(net); return PIVLFN_ERR_WEIGHTS; }
+        std::vector<float> w11((size_t)6 * 4 * 64 * 4), b11(192);
+        for (int blk = 0; blk < 6; ++blk)
+            for (int g = 0; g < 4; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 8 * g + 4 * (lane >> 5) + e, o = 32 * (blk < 2 ? blk : blk - 2) + (lane & 31);
+                        w11[(((size_t)blk * 4 + g) * 64 + lane) * 4 + e] = blk < 2 ? we->data[(size_t)o * 32 + c] : wf->data[(size_t)o * 32 + c];
+                    }
+        for (int o = 0; o < 64; ++o) b11[o] = be->data[o];
+        for (int o = 0; o < 128; ++o) b11[64 + o] = bfe->data[o];
+        TRY(upload(net, w11, &net->fuse1_w));
+        TRY(upload(net, b11, &net->fuse1_b));
     }
 #undef TRY
     if (hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking) != hipSuccess) {
@@ -852,8 +874,9 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         }
     } side_join{st, net->ev_join};
     const bool side_early = (PIV_KNOB(1) & 4096) != 0;                     // tools A/B: 4096 = each level's share right behind its NetC layer
+    bool fused1 = false;          // level 1's two 1 x 1 layers were computed inside NetC.conv1's kernel (below)
     auto side_level = [&](int L) -> int {
-        if (L < net->lowest || L > 4) return PIVLFN_OK;
+        if (L < net->lowest || L > 4 || (L == 1 && fused1)) return PIVLFN_OK;
         if (side != st) {
             PIV_CHECK_HIP(hipEventRecord(net->ev_fork[L], st));
             PIV_CHECK_HIP(hipStreamWaitEvent(side, net->ev_fork[L], 0));
@@ -867,7 +890,23 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     };
     // NetC on both frames as one batch of 2B (:325-326, Features.forward :108-116)
     const ConvW *nc = net->netc;
-    RUN(conv(nc[0], {{bf.img[1], 4, 4}}, bf.feat[1], 32, 32, nullptr, 0, 1, N2, h[1], w[1], 1, 3, 3, st));
+    // Level 1's NetC_ext (32 -> 64, both frames) and moduleFeat (32 -> 128, first frame) read nothing but conv1's output: in the fp32
+    // modes they are computed from conv1's activated accumulators in its own kernel -- their 1 GB of writes goes out under conv1's
+    // matrix work instead of beside the latency-bound chains of levels 6-4, and conv1's output is not read back twice.
+    if (net->lowest == 1 && net->fuse1_w && (t_precision == 0 || t_precision == 4) && !(PIV_KNOB(1) & 536870912)) {
+        ConvParams p1;
+        memset(&p1, 0, sizeof(p1));
+        p1.seg[0] = ConvSeg{bf.img[1], 4, 4}; p1.nseg = 1;
+        p1.wpk = nc[0].wpk; p1.bias = nc[0].bias; p1.out = bf.feat[1]; p1.out_stride = 32; p1.cout_store = 32; p1.cout_pad = nc[0].cout_pad;
+        p1.B = N2; p1.H = h[1]; p1.W = w[1]; p1.Ho = h[1]; p1.Wo = w[1];
+        p1.KH = 7; p1.KW = 7; p1.S = 1; p1.padY = 3; p1.padX = 3;
+        p1.nchunk = nc[0].nchunk; p1.tail = nc[0].tail; p1.lrelu = 1; p1.cin_real = nc[0].cin;
+        const Conv1Fuse f1{net->fuse1_w, net->fuse1_b, bf.ext[1], bf.featR[1], B};
+        const int rc1 = launch_conv1_fused(p1, f1, st);
+        if (rc1 > 0) return rc1;
+        fused1 = rc1 == 0;
+    }
+    if (!fused1) RUN(conv(nc[0], {{bf.img[1], 4, 4}}, bf.feat[1], 32, 32, nullptr, 0, 1, N2, h[1], w[1], 1, 3, 3, st));
     if (side_early) RUN(side_level(1));
     RUN(conv(nc[1], {{bf.feat[1], 32, 32}}, bf.sa, 32, 32, nullptr, 0, 1, N2, h[1], w[1], 2, 1, 1, st));
     RUN(conv(nc[2], {{bf.sa, 32, 32}}, bf.sb, 32, 32, nullptr, 0, 1, N2, h[2], w[2], 1, 1, 1, st));
@@ -912,7 +951,7 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
         // Join the side stream only where its results are first read: NetC_ext feeds Matching at levels <= 2, moduleFeat feeds
         // Regularization at levels 3 and 4.  (A cross-queue wait costs a barrier packet and a cold start for the next
         // kernel: in front of the level-3 warp+correlation it cost that launch 2 us.)
-        if (L <= 2) { PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0)); side_join.pending &= ~(1u << L); }
+        if (L <= 2 && !(L == 1 && fused1)) { PIV_CHECK_HIP(hipStreamWaitEvent(st, net->ev_join[L], 0)); side_join.pending &= ~(1u << L); }
         // ---- Matching (:165-187)
         const float *fup = nullptr;
         if (prev) {
