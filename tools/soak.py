@@ -20,7 +20,11 @@ nets = {(m, v): pivlfn.Network(model=m, params=synth.generate_weights(m + ("2" i
 cfgs = [(("piv", 1), 1, 256, 256, "fp32_split3"), (("piv", 1), 3, 96, 160, "fp32"), (("hui", 1), 2, 128, 192, "fp32_split3"),
         (("piv", 2), 1, 192, 128, "fp32_split"), (("piv", 1), 1, 512, 384, "fp16"), (("piv", 1), 2, 64, 64, "fp32_split3"),
         (("hui", 1), 1, 320, 256, "fp16"), (("piv", 1), 5, 128, 128, "fp32_split3"), (("piv", 1), 1, 1024, 1024, "fp32_split3"),
-        (("piv", 1), 2, 1024, 512, "fp32_split"), (("hui", 1), 1, 544, 800, "fp32_split3"), (("piv", 2), 2, 512, 512, "fp32_split3")]
+        (("piv", 1), 2, 1024, 512, "fp32_split"), (("hui", 1), 1, 544, 800, "fp32_split3"), (("piv", 2), 2, 512, 512, "fp32_split3"),
+        # the default arithmetic at sizes that take round 4's kernels (conv1 with the level-1 1 x 1 layers inside, the whole-line
+        # stride-2 kernel, the streaming distance convolutions, warp+correlation v6 / v7) and at sizes just below their bounds
+        (("piv", 1), 1, 1024, 1024, "fp32"), (("piv", 1), 2, 512, 768, "fp32"), (("hui", 1), 1, 1024, 512, "fp32"),
+        (("piv", 1), 1, 480, 544, "fp32"), (("piv", 1), 3, 256, 256, "fp32"), (("piv", 1), 1, 1024, 1024, "fp32_direct")]
 inputs, first = {}, {}
 for i, (key, B, H, W, prec) in enumerate(cfgs):
     a, b = synth.particle_batch(B, H, W, seed=70 + i)
