@@ -24,9 +24,10 @@ echo "pmc_wino done"
 # 5. counters of the separable distance convolutions (conv_col7 / conv_row7); micro-benchmarks: where the waves of a workgroup land,
 #    what a dependent chain of fp32 MFMAs sustains
 bash tools/pmc_dist.sh > $R/r04_pmc_dist.json 2> $R/pmc_dist.err || echo "pmc_dist failed"
-for m in wave_simd mfma_chain; do [ -x tools/micro/$m ] || hipcc --offload-arch=gfx950 -O3 tools/micro/$m.hip -o tools/micro/$m 2>/dev/null || true; done
+for m in wave_simd mfma_chain mfma_neighbour; do [ -x tools/micro/$m ] || hipcc --offload-arch=gfx950 -O3 tools/micro/$m.hip -o tools/micro/$m 2>/dev/null || true; done
 tools/micro/wave_simd > $R/r04_wave_simd.log 2>&1 || true
 tools/micro/mfma_chain > $R/r04_mfma_chain.log 2>&1 || true
+tools/micro/mfma_neighbour > $R/r04_mfma_neighbour.log 2>&1 || true
 python3 tools/bench_dist.py > $R/r04_bench_dist.log 2>&1 || true
 python3 tools/bench_s2.py > $R/r04_bench_s2.log 2>&1 || true
 python3 tools/bench_wino.py --levels 1 --layers 128x128,128x64,64x64,32x32 --rounds 3 > $R/r04_bench_wino_f4.log 2>&1 || true
