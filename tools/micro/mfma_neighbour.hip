@@ -10,7 +10,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 template <int SHAPE, bool DEP>
-__global__ __launch_bounds__(512, 1) void k(const float *src, float *dst, long long *ticks, int iters, int mfma_on)
+__global__ __launch_bounds__(512, 1) void k(const float *src, float *dst, long long *ticks, int iters, int mfma_on, int valu_iters)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -25,6 +25,7 @@ __global__ __launch_bounds__(512, 1) void k(const float *src, float *dst, long l
         f32x4 sm[4];
         for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) big[i][r] = 0.f;
         for (int i = 0; i < 4; ++i) sm[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const long long m0 = __builtin_readcyclecounter();
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -32,6 +33,8 @@ __global__ __launch_bounds__(512, 1) void k(const float *src, float *dst, long l
                 else { sm[q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, sm[q & 3], 0, 0, 0); sm[(q + 2) & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, sm[(q + 2) & 3], 0, 0, 0); }
             }
         }
+        const long long m1 = __builtin_readcyclecounter();
+        if (lane == 0) ticks[(blockIdx.x * 8 + wave) * 2] = m1 - m0;
         float s = 0.f;
         for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) s += big[i][r];
         for (int i = 0; i < 4; ++i) s += sm[i][0] + sm[i][1] + sm[i][2] + sm[i][3];
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(512, 1) void k(const float *src, float *dst, long l
     for (int i = 0; i < 2000; ++i) a = a * 1.0001f + 0.25f;
     const long long t0 = __builtin_readcyclecounter();
     float x0 = a, x1 = b, x2 = a + 1.f, x3 = b + 1.f, x4 = a + 2.f, x5 = b + 2.f, x6 = a + 3.f, x7 = b + 3.f;
-    for (int i = 0; i < 512; ++i) {
+    for (int i = 0; i < valu_iters; ++i) {
         if (DEP) { x0 = fmaf(x0, 1.0001f, 0.5f); x0 = fmaf(x0, 1.0001f, 0.5f); x0 = fmaf(x0, 1.0001f, 0.5f); x0 = fmaf(x0, 1.0001f, 0.5f);
                    x0 = fmaf(x0, 1.0001f, 0.5f); x0 = fmaf(x0, 1.0001f, 0.5f); x0 = fmaf(x0, 1.0001f, 0.5f); x0 = fmaf(x0, 1.0001f, 0.5f); }
         else { x0 = fmaf(x0, 1.0001f, 0.5f); x1 = fmaf(x1, 1.0001f, 0.5f); x2 = fmaf(x2, 1.0001f, 0.5f); x3 = fmaf(x3, 1.0001f, 0.5f);
@@ -54,11 +57,11 @@ __global__ __launch_bounds__(512, 1) void k(const float *src, float *dst, long l
 }
 
 template <int SHAPE, bool DEP>
-static void run(const float *src, float *dst, long long *ticks, int mfma_on, const char *what)
+static void run(const float *src, float *dst, long long *ticks, int mfma_on, const char *what, int valu_iters = 512)
 {
     const int nb = 256;
     (void)hipMemset(ticks, 0, nb * 8 * 2 * 8);
-    hipLaunchKernelGGL((k<SHAPE, DEP>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, 400, mfma_on);
+    hipLaunchKernelGGL((k<SHAPE, DEP>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, 400, mfma_on, valu_iters);
     (void)hipDeviceSynchronize();
     std::vector<long long> h(nb * 16);
     (void)hipMemcpy(h.data(), ticks, nb * 16 * 8, hipMemcpyDeviceToHost);
@@ -68,8 +71,11 @@ static void run(const float *src, float *dst, long long *ticks, int mfma_on, con
             const int simd = (int)(h[(b * 8 + w) * 2 + 1] & 3);
             bool beside_mfma = false;
             for (int v = 0; v < 4; ++v) beside_mfma |= (int)(h[(b * 8 + v) * 2 + 1] & 3) == simd;
-            s[beside_mfma] += (double)h[(b * 8 + w) * 2]; n[beside_mfma]++;
+            s[beside_mfma] += (double)h[(b * 8 + w) * 2] * 512.0 / valu_iters; n[beside_mfma]++;
         }
+    double ms = 0; int mn = 0;
+    for (int b = 0; b < nb; ++b) for (int w = 0; w < 4; ++w) if (h[(b * 8 + w) * 2] > 0) { ms += (double)h[(b * 8 + w) * 2]; ++mn; }
+    if (mn) printf("    MFMA waves: %.1f cycles per %s (n=%d)\n", ms / mn / (400.0 * 16), SHAPE == 32 ? "32x32x2 instruction" : "pair of 16x16x4 instructions", mn);
     printf("%-44s SIMD partner is a vector wave: %6.1f cycles per instruction (n=%d);  an MFMA wave%s: %6.1f (n=%d)\n", what,
            n[0] ? s[0] / n[0] / 4096.0 : 0.0, n[0], mfma_on ? "" : " (idle here)", n[1] ? s[1] / n[1] / 4096.0 : 0.0, n[1]);
 }
@@ -87,5 +93,9 @@ int main()
     run<32, false>(src, dst, ticks, 0, "independent fmas, MFMA waves idle");
     run<32, false>(src, dst, ticks, 1, "independent fmas, 32x32x2 MFMAs");
     run<16, false>(src, dst, ticks, 1, "independent fmas, 16x16x4 MFMAs");
+    printf("-- the vector chains as long as the MFMA loops (the MFMA waves' own pace, first with a short chain beside them):\n");
+    run<32, false>(src, dst, ticks, 1, "independent fmas x 40, 32x32x2 MFMAs", 512 * 40);
+    run<32, true>(src, dst, ticks, 1, "dependent chain x 20, 32x32x2 MFMAs", 512 * 20);
+    run<16, false>(src, dst, ticks, 1, "independent fmas x 40, 16x16x4 MFMAs", 512 * 40);
     return 0;
 }
