@@ -219,10 +219,10 @@ def conv_roofline(dev, precision, launches=40):
         return {"bound": "mfma", "achieved": round(ex / t / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ex / t / 157.3e12, 4), "traffic": None,
                 "kernel": "conv_wino_kernel<1, 2>, 128->128 3x3 at 1024x1024 B=1 (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                 "direct_equivalent_tflops": round(flop / t / 1e12, 1), **spread,
-                "note": "achieved = fp32 matrix work actually executed (2 x 16/4 x pixels x Cin x Cout) / median duration; the fp32 MFMA shares the SIMD's "
-                        "fp32 datapath with the vector instructions of the input / output transforms (no co-execution: profiles/r04_pmc_wino_insts.json: "
-                        "1.5 vector instructions per MFMA), the matrix pipe is busy ~73 % of the launch (profiles/r04_pmc_wino_busy.json, clock from "
-                        "GRBM_GUI_ACTIVE / duration in the same file)"}
+                "note": "achieved = fp32 matrix work actually executed (2 x 16/4 x pixels x Cin x Cout) / median duration; a wave's own vector "
+                        "instructions (input / output transforms: 1.66 per MFMA, profiles/r04_pmc_wino_insts.json) delay its next MFMA -- in-order issue; "
+                        "vector work of another wave of the SIMD does not (profiles/r04_mfma_neighbour.log) -- and the matrix pipe is busy ~75 % of the "
+                        "launch (profiles/r04_pmc_wino_busy.json, clock from GRBM_GUI_ACTIVE / duration in the same file)"}
     return {"bound": "mfma", "achieved": round(flop / t / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(flop / t / 157.3e12, 4), "traffic": None,
             "kernel": "conv_mfma2_kernel, 128->128 3x3 at 1024x1024 B=1 (v_mfma_f32_32x32x2_f32)", **spread}
 
