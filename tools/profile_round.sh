@@ -24,6 +24,7 @@ echo "pmc_wino done"
 # 5. counters of the separable distance convolutions (conv_col7 / conv_row7); micro-benchmarks: where the waves of a workgroup land,
 #    what a dependent chain of fp32 MFMAs sustains
 bash tools/pmc_dist.sh > $R/r04_pmc_dist.json 2> $R/pmc_dist.err || echo "pmc_dist failed"
+bash tools/pmc_netc.sh > $R/r04_pmc_netc.json 2> $R/pmc_netc.err || echo "pmc_netc failed"
 for m in wave_simd mfma_chain mfma_neighbour; do [ -x tools/micro/$m ] || hipcc --offload-arch=gfx950 -O3 tools/micro/$m.hip -o tools/micro/$m 2>/dev/null || true; done
 tools/micro/wave_simd > $R/r04_wave_simd.log 2>&1 || true
 tools/micro/mfma_chain > $R/r04_mfma_chain.log 2>&1 || true
