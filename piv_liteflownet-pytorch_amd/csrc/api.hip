@@ -29,6 +29,19 @@ int ensure_dyn_lds(LdsAttr &slot, const void *fn, int bytes)
     return PIVLFN_OK;
 }
 
+int device_cus()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_ACQUIRE);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELEASE);
+    }
+    return n;
+}
+
 void set_error(const char *fmt, ...)
 {
     va_list ap;

@@ -5,7 +5,7 @@
 #                     stamps); only tools/*.py load it
 set -e
 cd "$(dirname "$0")"
-SRCS="conv_mfma conv_wino conv_wino4 conv_f16 conv_split conv_head warp_corr corr_bwd ops net api"
+SRCS="conv_mfma conv_wino conv_wino_ws conv_wino4 conv_f16 conv_split conv_head warp_corr corr_bwd ops net api"
 build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags
   local OBJ="$1" OUT="$2"
   mkdir -p "$OBJ"

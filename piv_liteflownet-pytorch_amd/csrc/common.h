@@ -42,6 +42,8 @@ int ensure_dyn_lds(LdsAttr &slot, const void *fn, int bytes);
         }                                                                                    \
     } while (0)
 
+int device_cus();      // compute units of the current device (cached per device; 256 when the query fails)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch over the 8 XCDs); give every XCD a contiguous
@@ -184,8 +186,11 @@ struct ConvParamsW {
     int B, H, W;        // output grid = input grid (3x3, stride 1, pad 1)
     int nchunk, lrelu;
     unsigned long long *stamps;   // tools build (-DPIVLFN_STAMPS) only: per-workgroup phase times of wave 0 (s_memtime ticks), 8 per workgroup; nullptr in production
+    int dbg;            // tools build only: ablation mask of conv_wino_ws.hip (timing runs, wrong results)
 };
 int launch_conv_w(const ConvParamsW &p, hipStream_t st);
+int launch_conv_w_ws(const ConvParamsW &p, hipStream_t st);   // the same layers on persistent workgroups with producer / consumer waves (conv_wino_ws.hip); bit-identical
+long conv_wino_ws_items(const ConvParamsW &p);                // work items such a launch would have (0: not covered)
 int launch_conv_w4(const ConvParamsW &p, hipStream_t st);      // F(4x4, 3x3): wpk = [nchunk][cout_pad/32][6][6][64][4] (pack_conv_w4)
 bool conv_wino_supports(int KH, int KW, int S, int padY, int padX);
 // 32 -> 2 channel k x k flow head on the VALU (conv_head.hip); w = [k*k][8][2][4] on the device

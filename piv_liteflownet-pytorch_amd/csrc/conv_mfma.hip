@@ -779,8 +779,7 @@ static int launch_conv_c3k7(const ConvParams &p, hipStream_t st)
         return -1;
     const long tiles = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B;
     if ((long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) < 512) return -1;             // per image: never a function of the batch
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     hipLaunchKernelGGL((conv_c3k7_kernel<false>), dim3((unsigned)std::min<long>(tiles, 3L * cus)), dim3(256), 0, st, p, Conv1Fuse{});
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
@@ -794,8 +793,7 @@ int launch_conv1_fused(const ConvParams &p, const Conv1Fuse &f, hipStream_t st)
         return -1;
     if ((long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) < 512) return -1;             // per image: never a function of the batch
     const long tiles = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     hipLaunchKernelGGL((conv_c3k7_kernel<true>), dim3((unsigned)std::min<long>(tiles, 2L * cus)), dim3(256), 0, st, p, f);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
@@ -960,8 +958,7 @@ static int launch_conv_s2(const ConvParams &p_in, hipStream_t st)
     if ((size_t)17 * p.W * p.seg[0].stride * 4 >= 0x7fffffffull) return -1;       // one patch inside a descriptor's 2 GiB
     const int nt = p.cout_pad / 32;
     const size_t lds = ((size_t)S2_NPIX * S2_PIXP + (size_t)4 * 9 * 2 * 32 * nt * 4) * sizeof(float);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     const long tiles = (long)cdiv(p.Wo, 16) * cdiv(p.Ho, 8) * p.B;
     const dim3 grid((unsigned)std::min<long>(tiles, cus), 1);
     static LdsAttr attr1, attr2;

@@ -1327,19 +1327,6 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
     store_tile(launder(tp), Tprev, true);          // the last unit of a workgroup is always a tile
 }
 
-static int device_cus()
-{
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int n = __atomic_load_n(&cus[dev], __ATOMIC_ACQUIRE);
-    if (n == 0) {
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        __atomic_store_n(&cus[dev], n, __ATOMIC_RELEASE);
-    }
-    return n;
-}
-
 template <bool HASFLOW, int NS>
 static int launch_wc6_ns(const WcParams &p, int nblk, hipStream_t st)
 {

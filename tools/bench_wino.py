@@ -62,6 +62,48 @@ def stamps(a):
             lib.pivlfn_conv_destroy(h)
 
 
+def ws_stamps(a):
+    """Wave-specialised kernel (conv_wino_ws.hip): ticks of consumer wave 0 and producer wave 4 of every workgroup."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _toolslib
+    lib = _toolslib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    layers = [tuple(int(v) for v in s.split("x")) for s in a.layers.split(",")] if a.layers else [(128, 128)]
+    for L in [int(x) for x in a.levels.split(",")]:
+        n = a.size >> (L - 1)
+        for ci, co in layers:
+            g = torch.Generator().manual_seed(ci * 7 + co)
+            w = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).contiguous()
+            b = torch.randn(co, generator=g).contiguous()
+            h = ctypes.c_void_p()
+            _lib.check(lib.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(h)), "create")
+            xs = -(-ci // 4) * 4
+            x = torch.randn(a.batch, n, n, xs, device=dev)
+            y = torch.empty(a.batch, n, n, co, device=dev)
+            buf = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
+            lib.pivlfn_tune(14, 31)
+            for dbg in [int(v) for v in (a.masks or "0").split(",")]:
+                lib.pivlfn_tune(15, dbg)
+                for _ in range(3):
+                    _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y.data_ptr(), co, a.batch, n, n, 1, st), "wino")
+                buf.zero_()
+                _toolslib.set_stamp_buffer(lib, buf.data_ptr())
+                _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, y.data_ptr(), co, a.batch, n, n, 1, st), "wino")
+                torch.cuda.synchronize()
+                _toolslib.set_stamp_buffer(lib, 0)
+                t = buf.view(-1, 16).cpu().numpy().astype(float)
+                t = t[t[:, 3] > 0]
+                nch = -(-ci // 8)
+                steps = t[:, 5] * nch
+                print(f"L{L} {ci}->{co} dbg {dbg}: {len(t)} workgroups, {t[:, 5].mean():.1f} items x {nch} chunks; per step (ticks, mean over workgroups): "
+                      f"consumer: whole {(t[:, 3] / steps).mean():.0f}  MFMA+refills {(t[:, 0] / steps).mean():.0f}  column half {(t[:, 1] / steps).mean():.0f}  barrier {(t[:, 2] / steps).mean():.0f} | "
+                      f"producer: whole {(t[:, 11] / steps).mean():.0f}  load wait+commit {(t[:, 9] / steps).mean():.0f}  rest of its work {(t[:, 8] / steps).mean():.0f}  barrier {(t[:, 10] / steps).mean():.0f}", flush=True)
+            lib.pivlfn_tune(15, 0)
+            lib.pivlfn_tune(14, 0)
+            lib.pivlfn_conv_destroy(h)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1024)
@@ -72,10 +114,13 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--ab", default="", help="path of a second build of libpivlfn.so: its Winograd kernel is timed beside the current one (interleaved rounds)")
     ap.add_argument("--w4", action="store_true", help="--masks are ablation masks of the F(4x4) kernel (1 no MFMAs, 2 no transform, 4 no weight loads, 8 no patch loads, 16 no epilogue)")
-    ap.add_argument("--masks", default="", help="tools build only: per-variant masks of the Winograd kernel: (m >> 8) & 255 = forced tile shape (11, 21, 22, 14), 65536 = one workgroup per CU")
+    ap.add_argument("--masks", default="", help="tools build only: per-variant masks of the Winograd kernel: (m >> 8) & 255 = forced tile shape (11, 21, 22, 14; 30 = never / 31 = always the wave-specialised kernel), 65536 = one workgroup per CU, m >> 24 = ablation mask of the wave-specialised kernel")
     ap.add_argument("--stamps", action="store_true", help="tools build only: phase times of wave 0 of every workgroup (s_memtime ticks) for the two-block shape, at two and at one workgroup per CU")
+    ap.add_argument("--ws-stamps", action="store_true", help="tools build only: barrier / load-wait ticks of the wave-specialised kernel; --masks = its ablation masks")
     a = ap.parse_args()
     lib = _lib.load()
+    if a.ws_stamps:
+        return ws_stamps(a)
     if a.stamps:
         return stamps(a)
     if a.masks:
@@ -133,8 +178,10 @@ def main():
                             return
                         lib.pivlfn_tune(13, m & 255)
                         lib.pivlfn_tune(14, (m >> 8) & 255)
-                        lib.pivlfn_tune(1, (m >> 16) << 20)
+                        lib.pivlfn_tune(1, ((m >> 16) & 255) << 20)
+                        lib.pivlfn_tune(15, (m >> 24) & 255)
                         wino()
+                        lib.pivlfn_tune(15, 0)
                         lib.pivlfn_tune(13, 0)
                         lib.pivlfn_tune(14, 0)
                         lib.pivlfn_tune(1, 0)
