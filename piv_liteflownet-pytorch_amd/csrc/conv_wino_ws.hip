@@ -1,28 +1,30 @@
-// Winograd F(2x2, 3x3) with specialised waves: persistent workgroups of eight waves, four that only multiply and four that do
-// everything else.
+// Winograd F(2x2, 3x3) on persistent workgroups with specialised waves: four waves that transform and multiply, four that move data.
 //
 // Same layers, same packed weights, same arithmetic and the same summation order per output value as conv_wino.hip (chunks
 // ascending, k = {j, 4 + j} inside a chunk, the output transform's additions in the same order): the results are bit-identical to
-// that kernel's, so which of the two runs a layer may follow the launch size.  What changes is who issues what.  In conv_wino.hip
-// every wave loads, transforms, multiplies and stores, and on gfx950 a wave issues in order: each vector instruction in front of a
-// v_mfma_f32_32x32x2_f32 is ~4 cycles in which that wave's SIMD starts no matrix work (1.66 vector instructions per MFMA, prologue
-// and epilogue per workgroup: the matrix pipe is busy 75 % of a launch).  A vector instruction of ANOTHER wave of the SIMD costs the
-// matrix pipe nothing (tools/micro/mfma_neighbour.hip: the MFMA wave keeps 64.0 cycles per instruction beside a vector wave).  So:
+// that kernel's, so which of the two runs a layer may follow the launch size.  What changes is who issues what, and when.
 //
-//   * One workgroup per CU (persistent, 512 threads): waves 0-3 -- one per SIMD -- are CONSUMERS, waves 4-7 -- again one per SIMD --
-//     are PRODUCERS.  Consumer i owns plane row i (planes (i, 0..3)) of a 32-tile x 32 NBW-channel work item, as in conv_wino.hip.
-//   * A consumer's K step is 16 NBW MFMAs per plane row and, behind each plane's MFMAs, the refill of exactly the registers that plane
-//     just read: one ds_read_b128 of the next chunk's transformed operand V (written by the producers) and NBW buffer loads of the next
-//     chunk's weight fragments (fragment order, L2-resident, scalar offsets: no address arithmetic).  No transform, no staging, no
-//     vector instruction in the loop.
-//   * The producers run ahead of the consumers through two rings in LDS: raw 8-channel patches (global -> registers -> LDS,
-//     de-interleaved image of wino_common.h) and transformed operands V = B^T d B (16 planes x 64 lanes x 16 bytes per chunk).
-//     Producer wave i forms plane row i for consumer i.  One s_barrier per K step is the only synchronisation: at the barrier that
-//     ends step c, V(c + 2) is complete and V(c)'s slot is free.
+// In conv_wino.hip every wave loads its share of the patch, commits it to LDS, transforms, multiplies and stores, and a workgroup
+// lives for one tile: of a launch's time 9 % is the patch traffic issued between the MFMAs and 11-30 % the workgroup's prologue
+// and epilogue.  Here:
+//   * One workgroup per CU (persistent, 512 threads).  Waves 0-3 -- one per SIMD -- are CONSUMERS: consumer i owns plane row i
+//     (planes (i, 0..3)) of a 32-tile x 32 NBW-channel work item, as a wave of conv_wino.hip does, and its K step is that kernel's
+//     without the staging: 16 NBW MFMAs, the raw operand reads of the NEXT chunk from LDS, its transform (16 packed instructions)
+//     and the weight fragments of the next chunk (buffer loads with scalar offsets behind each plane's MFMAs, into the registers that
+//     plane just read).
+//   * Waves 4-7 -- again one per SIMD -- are PRODUCERS: global -> registers -> LDS (two steps of latency cover, two register sets)
+//     for the raw-patch ring, and the stores.  Their steady state contains NO vector instruction: on this chip a vector instruction
+//     of the second wave of a SIMD is not executed beside a wave that streams fp32 MFMAs and meets it at barriers -- it waits until
+//     that wave pauses (tools/micro/ws_step.hip, ws_gap.hip: LDS writes, scalar work and loads of the second wave are free, its
+//     vector work adds its whole duration to the step; round 5's first version, whose producers also transformed, ran at 0.60 of
+//     the matrix peak for that reason).  So the per-lane load offsets are constants (interior items: the descriptor starts at the
+//     patch's first pixel) chosen by scalar branches, the LDS addresses are registers plus immediates, and everything that needs the
+//     vector unit -- the offsets of an item that touches the image border, and the row half of the output transform with bias and
+//     LeakyReLU -- happens ONCE per item, in the step where the consumers wait for it anyway.
 //   * The work items of a workgroup (tile x channel group; its XCD's band, interleaved over the XCD's CUs) form ONE step sequence:
-//     the producers' loads are four steps ahead and cross item boundaries, so a consumer goes from the last MFMA of an item to the
-//     first of the next with only the column half of the output transform in between (it writes R = M A to LDS); the row half,
-//     bias, LeakyReLU and the stores of item k are producer work during the first step of item k + 1.
+//     the producers' loads run four chunks ahead and cross item boundaries, so a consumer goes from the last MFMA of an item to the
+//     first of the next with only the column half of the output transform in between (it writes R = M A to LDS).
+//   * One s_barrier per K step hands the raw ring over: at the barrier that ends step c, raw(c + 2) is in LDS and raw(c)'s slot free.
 #include <algorithm>
 #include "common.h"
 #include "wino_common.h"
@@ -35,9 +37,8 @@ constexpr int WS_PH = 10;                              // patch rows of an 8 x 4
 constexpr int WS_NSLOT = WS_PH * WPW * 2;              // 16-byte staging slots of one chunk's patch (360)
 constexpr int WS_PS = 2;                               // slots per producer thread
 constexpr int WS_PBUF = WS_PH * WROWQ + WPIXQ;         // quads per raw patch buffer (+ one spare record)
-constexpr int WS_VQ = 1152;                            // quad offset of the V ring (3 x 1024 quads)
-constexpr int WS_XQ = WS_VQ + 3072;                    // quad offset of the output-transform exchange (NBW x 2048 quads)
-static_assert(2 * WS_PBUF <= WS_VQ, "raw ring overlaps the V ring");
+constexpr int WS_XQ = 1152;                            // quad offset of the output-transform exchange (NBW x 2048 quads)
+static_assert(2 * WS_PBUF <= WS_XQ, "raw ring overlaps the exchange area");
 
 }  // namespace
 
@@ -68,13 +69,18 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
     }
 
     const int tid = threadIdx.x;
+    // the layer's bias lives in LDS (behind the exchange area) for the life of the workgroup: the item's last step must not wait on
+    // a global load that queues behind the patch loads in flight
+    const int bias_q = WS_XQ + NBW * 2048;
+    for (int i = tid; i < p.cout_pad; i += 512) smem[bias_q * 4 + i] = p.bias[i];
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, g = lane >> 5;
+    const int tyl = n >> 3, txl = n & 7;
     float m1 = -1.f;
     asm("" : "+v"(m1));
 #ifdef PIVLFN_STAMPS
-    // tools build: ablation mask p.dbg (1 no patch loads, 2 no weight refills, 4 no V refills, 8 no finish_item, 16 no column half,
+    // tools build: ablation mask p.dbg (1 no patch loads, 2 no weight refills, 4 no raw reads, 8 no finish_item, 16 no column half,
     // 32 no transform) and per-workgroup stamps of wave 0 (consumer) and wave 4 (producer): ticks spent waiting at the step barriers
     const int dbg = p.dbg;
     const bool stamp_ = p.stamps != nullptr && (wave == 0 || wave == 4) && blockIdx.x < 4096;
@@ -99,37 +105,77 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
         __syncthreads();                                                                          \
         WS_STAMP(d_bar_);                                                                         \
     } while (0)
+    auto decode = [&](int s, int &b, int &y0, int &x0, int &nb0) {
+        int t = t0 + s * tstep;
+        nb0 = (t % NG) * NBW;
+        t /= NG;
+        x0 = (t % tiles_x) * 16;
+        t /= tiles_x;
+        y0 = (t % tiles_y) * 8;
+        b = t / tiles_y;
+    };
 
     if (wave < 4) {
         // ------------------------------------------------------------------------------------------------ consumer, plane row `wave`
-        if (!WS_DBG(64)) __builtin_amdgcn_s_setprio(3);
         f32x16 acc[4][NBW];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x4 V[4], Wt[NBW][4];
+        f32x4 V[4], Wt[NBW][4], raw[8] = {}, tt[4];
         // weights of (chunk, block nb, plane row i): 4 planes x 64 lanes x 16 bytes, contiguous: byte offset ((chunk NB + nb) 4 + i) 4096
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wpk), 0,
                                                                             (unsigned)((size_t)nchunk * NB * 16 * 1024), 0x00020000);
         const int wvoff = lane * 16;
         const int wstep = NB * 4 * 4096;              // bytes from one chunk to the next
-        const int vlane = WS_VQ + wave * 256 + lane;  // quad index of the lane's operand of plane (wave, 0) in V slot 0
+        // plane row i = wave: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]
+        const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+        const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+        const float sb = wave == 1 ? 1.f : -1.f;
+        const int abase = (tyl + (ra >> 1) + (ra & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g;      // patch pixel (2 tyl + ra, 2 txl), in quads
+        const int bbase = (tyl + (rb >> 1) + (rb & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g;
 
-#define WS_REFILL(JP, VSLOT, SOFF)                                                                \
+#define WS_MFMA(JP, Z)                                                                            \
     do {                                                                                          \
-        if (!WS_DBG(4)) V[JP] = smem4[vlane + (VSLOT)*1024 + (JP)*64];                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            _Pragma("unroll") for (int nw = 0; nw < NBW; ++nw)                                    \
+                acc[JP][nw] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wt[nw][JP][j], V[JP][j], ((Z) && j == 0) ? zero16 : acc[JP][nw], 0, 0, 0); \
+    } while (0)
+#define WS_REFILLW(JP, SOFF)                                                                      \
+    do {                                                                                          \
         if (!WS_DBG(2)) _Pragma("unroll") for (int nw = 0; nw < NBW; ++nw)                        \
             Wt[nw][JP] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff + (JP)*1024, (SOFF) + nw * 16384, 0)); \
     } while (0)
-// One K step: per plane 4 NBW MFMAs (k pairs ascending), then the refill of that plane's registers for the next step.
-#define WS_CSTEP(Z, VSLOT, SOFF)                                                                  \
+// the lane's 8 operand quads (rows ra, rb x columns 0..3 of its tile's patch) from the raw patch at quad offset RQ
+#define WS_READRAW(RQ)                                                                            \
     do {                                                                                          \
-        _Pragma("unroll") for (int jp = 0; jp < 4; ++jp) {                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
-                _Pragma("unroll") for (int nw = 0; nw < NBW; ++nw)                                \
-                    acc[jp][nw] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wt[nw][jp][j], V[jp][j], ((Z) && j == 0) ? zero16 : acc[jp][nw], 0, 0, 0); \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            WS_REFILL(jp, VSLOT, SOFF);                                                           \
+        if (!WS_DBG(4)) _Pragma("unroll") for (int c = 0; c < 4; ++c) {                           \
+            raw[c] = smem4[(RQ) + abase + ((c >> 1) + (c & 1) * 9) * WPIXQ];                      \
+            raw[4 + c] = smem4[(RQ) + bbase + ((c >> 1) + (c & 1) * 9) * WPIXQ];                  \
         }                                                                                         \
+    } while (0)
+// One K step: chunk c's MFMAs plane by plane; behind plane jp's MFMAs the refill of that plane's weight registers with chunk c + 1
+// and a quarter of chunk c + 1's transform, V = (B^T d B)[wave][0..3] written in place (a plane's operand is dead once its MFMAs
+// are issued): raw reads behind plane 0, the row combination behind plane 1, columns 0-1 behind plane 2, columns 2-3 behind plane 3.
+#define WS_CSTEP(Z, RQ, SOFF)                                                                     \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_MFMA(0, Z);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_REFILLW(0, SOFF);                                                                      \
+        WS_READRAW(RQ);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_MFMA(1, Z);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_REFILLW(1, SOFF);                                                                      \
+        if (!WS_DBG(32)) _Pragma("unroll") for (int c = 0; c < 4; ++c) tt[c] = sub4(raw[c], raw[4 + c], sb); \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_MFMA(2, Z);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_REFILLW(2, SOFF);                                                                      \
+        if (!WS_DBG(32)) { V[0] = sub4(tt[0], tt[2], m1); V[1] = tt[1] + tt[2]; }                 \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_MFMA(3, Z);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WS_REFILLW(3, SOFF);                                                                      \
+        if (!WS_DBG(32)) { V[2] = sub4(tt[2], tt[1], m1); V[3] = sub4(tt[1], tt[3], m1); }        \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
 
@@ -137,31 +183,35 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
             const int t = t0 + s * tstep;
             return (((t % NG) * NBW) * 4 + wave) * 4096;
         };
-        WS_SYNC();      // step -4: raw(0) committed
-        WS_SYNC();      // step -3: V(0) written ...
-        WS_SYNC();      // step -2: ... and complete
         int woff = item_woff(0);
 #pragma unroll
-        for (int jp = 0; jp < 4; ++jp) WS_REFILL(jp, 0, woff);
-        WS_SYNC();      // step -1
-        int vslot = 1;        // V slot the next refills read (chunk index modulo 3)
-#define WS_NEXT_VSLOT() vslot = vslot == 2 ? 0 : vslot + 1
+        for (int jp = 0; jp < 4; ++jp) WS_REFILLW(jp, woff);
+        WS_SYNC();      // step -2: raw(0) committed
+        WS_READRAW(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tt[c] = sub4(raw[c], raw[4 + c], sb);
+        V[0] = sub4(tt[0], tt[2], m1);
+        V[1] = tt[1] + tt[2];
+        V[2] = sub4(tt[2], tt[1], m1);
+        V[3] = sub4(tt[1], tt[3], m1);
+        WS_SYNC();      // step -1: raw(1) committed
+        int rq = WS_PBUF;     // quad offset of the raw slot the next step reads (chunk c + 1)
         for (int s = 0; s < n_items; ++s) {
             const bool more = s + 1 < n_items;
             const int woff_next = more ? item_woff(s + 1) : 0;
             int soff = woff + wstep;
-            WS_CSTEP(true, vslot, soff);
+            WS_CSTEP(true, rq, soff);
             WS_SYNC();
-            WS_NEXT_VSLOT();
+            rq ^= WS_PBUF;
             for (int c = 1; c + 1 < nchunk; ++c) {
                 soff += wstep;
-                WS_CSTEP(false, vslot, soff);
+                WS_CSTEP(false, rq, soff);
                 WS_SYNC();
-                WS_NEXT_VSLOT();
+                rq ^= WS_PBUF;
             }
-            // last chunk: the refills fetch the next item's first chunk (past the end: this chunk again, nobody uses it)
+            // last chunk: the refills and the transform are those of the next item's first chunk (past the end: nobody uses them)
             soff = more ? woff_next : soff;
-            WS_CSTEP(false, vslot, soff);
+            WS_CSTEP(false, rq, soff);
             // column half of the output transform: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 -> LDS [nw][plane row][q][rg][lane]
             f32x4 *xch = smem4 + WS_XQ;
             WS_STAMP(d_a_);
@@ -179,7 +229,7 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
                 }
             WS_STAMP(d_b_);
             WS_SYNC();
-            WS_NEXT_VSLOT();
+            rq ^= WS_PBUF;
             woff = woff_next;
         }
 #ifdef PIVLFN_STAMPS
@@ -189,89 +239,80 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
         }
 #endif
 #undef WS_CSTEP
-#undef WS_REFILL
-#undef WS_NEXT_VSLOT
+#undef WS_MFMA
+#undef WS_REFILLW
+#undef WS_READRAW
         return;
     }
 
-    // ---------------------------------------------------------------------------------------------------- producer, plane row `pw`
+    // ---------------------------------------------------------------------------------------------------- producer
     const int pw = wave - 4;
     const int ptid = tid - 256;
-    if (WS_DBG(128)) __builtin_amdgcn_s_setprio(3);
-    // staging slots of this thread: slot s covers (pixel, quad) = (idx >> 1, idx & 1), idx = ptid + 256 s (conv_wino.hip)
+    // staging slots of this thread: slot k covers (pixel, quad) = (idx >> 1, idx & 1), idx = ptid + 256 k (conv_wino.hip)
     int plds[WS_PS], ppy[WS_PS], ppx[WS_PS];
     const int q4 = (ptid & 1) * 4;
 #pragma unroll
-    for (int s = 0; s < WS_PS; ++s) {
-        const int idx = ptid + 256 * s;
+    for (int k = 0; k < WS_PS; ++k) {
+        const int idx = ptid + 256 * k;
         const int pix = idx >> 1;
         const int py = pix / WPW, px = pix - py * WPW;
-        ppy[s] = idx < WS_NSLOT ? py : -100000;
-        ppx[s] = px;
-        plds[s] = (idx < WS_NSLOT ? ((py >> 1) + (py & 1) * (WS_PH / 2)) * WROWQ + ((px >> 1) + (px & 1) * 9) * WPIXQ : WS_PH * WROWQ) + (ptid & 1);
+        ppy[k] = idx < WS_NSLOT ? py : -100000;
+        ppx[k] = px;
+        plds[k] = (idx < WS_NSLOT ? ((py >> 1) + (py & 1) * (WS_PH / 2)) * WROWQ + ((px >> 1) + (px & 1) * 9) * WPIXQ : WS_PH * WROWQ) + (ptid & 1);
     }
-    // plane row i = pw: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]
-    const int ra = pw == 0 ? 0 : (pw == 2 ? 2 : 1);
-    const int rb = pw == 0 ? 2 : (pw == 1 ? 2 : (pw == 2 ? 1 : 3));
-    const float sb = pw == 1 ? 1.f : -1.f;
-    const int tyl = n >> 3, txl = n & 7;
-    const int abase = (tyl + (ra >> 1) + (ra & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g;      // patch pixel (2 tyl + ra, 2 txl), in quads
-    const int bbase = (tyl + (rb >> 1) + (rb & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g;
-    const int vlane = WS_VQ + pw * 256 + lane;
 
-    // ---- load cursor: the (item, chunk) whose raw patch is fetched next, and everything its load needs -- descriptor, scalar channel
-    // offset and the per-slot byte offsets -- computed one step ahead, in the vector section of the step before
+    // ---- load cursor: the (item, chunk) whose raw patch is fetched next.  Everything a load needs is scalar -- descriptor, channel
+    // offset -- or a register computed once: per-lane byte offsets of the slot's pixel inside an INTERIOR item's patch, whose descriptor
+    // starts at the patch's first pixel (iv*), and, for an item that touches the image border, offsets from the first image row of
+    // its patch with out-of-range values for the zero padding (bv*: vector work, done when the cursor enters such an item).  `*t` are
+    // the versions for a source's 4-channel tail chunk (the upper quad loads zeros).
     const size_t img_px = (size_t)p.H * p.W;
     int l_item = 0, l_chunk = 0, l_seg = 0, l_c0 = 0;
-    // per-source constants and descriptors as plain scalars (an array indexed by the run-time source goes to scratch memory and
-    // takes the whole cursor into vector registers with it)
     const int scl0 = p.seg[0].cload, scl1 = p.seg[p.nseg > 1 ? 1 : 0].cload, scl2 = p.seg[p.nseg > 2 ? 2 : 0].cload;
     const int sst40 = p.seg[0].stride * 4, sst41 = p.seg[p.nseg > 1 ? 1 : 0].stride * 4, sst42 = p.seg[p.nseg > 2 ? 2 : 0].stride * 4;
     __amdgpu_buffer_rsrc_t rs0, rs1, rs2;
-    unsigned ppix[WS_PS];
-    auto decode = [&](int s, int &b, int &y0, int &x0, int &nb0) {
-        int t = t0 + s * tstep;
-        nb0 = (t % NG) * NBW;
-        t /= NG;
-        x0 = (t % tiles_x) * 16;
-        t /= tiles_x;
-        y0 = (t % tiles_y) * 8;
-        b = t / tiles_y;
-    };
-    // the descriptor of source SS for the item whose patch starts at image row row0 of image b: it starts at that row (64-bit
-    // scalar arithmetic), the 32-bit per-lane offsets only span the patch rows
-#define WS_MAKE_RS(SS, B_, ROW0)                                                                  \
-    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[SS].ptr + ((size_t)(B_)*img_px + (size_t)(ROW0)*p.W) * p.seg[SS].stride), 0, \
-                                      (unsigned)min((((size_t)(p.H - (ROW0)) * p.W - 1) * p.seg[SS].stride + p.seg[SS].cload) * 4, (size_t)0x7fffffff), 0x00020000)
+    bool l_border = false;
+    unsigned iv0[WS_PS], iv1[WS_PS], iv2[WS_PS], iv0t[WS_PS], iv1t[WS_PS], iv2t[WS_PS];
+    unsigned bv0[WS_PS] = {}, bv1[WS_PS] = {}, bv2[WS_PS] = {}, bv0t[WS_PS] = {}, bv1t[WS_PS] = {}, bv2t[WS_PS] = {};
+#pragma unroll
+    for (int k = 0; k < WS_PS; ++k) {
+        const unsigned pix = ppy[k] >= 0 ? (unsigned)(ppy[k] * p.W + ppx[k]) : WOOB;
+        iv0[k] = pix != WOOB ? pix * (unsigned)sst40 + (unsigned)q4 * 4u : WOOB;
+        iv1[k] = pix != WOOB ? pix * (unsigned)sst41 + (unsigned)q4 * 4u : WOOB;
+        iv2[k] = pix != WOOB ? pix * (unsigned)sst42 + (unsigned)q4 * 4u : WOOB;
+        iv0t[k] = q4 ? WOOB : iv0[k];
+        iv1t[k] = q4 ? WOOB : iv1[k];
+        iv2t[k] = q4 ? WOOB : iv2[k];
+    }
+    // descriptor of source SS starting at pixel (B_, ROW, COL): 64-bit scalar arithmetic; it ends with the image
+#define WS_MAKE_RS(SS, B_, ROW, COL)                                                              \
+    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[SS].ptr + ((size_t)(B_)*img_px + (size_t)(ROW)*p.W + (COL)) * p.seg[SS].stride), 0, \
+                                      (unsigned)min((((size_t)(p.H - (ROW)) * p.W - (COL) - 1) * p.seg[SS].stride + p.seg[SS].cload) * 4, (size_t)0x7fffffff), 0x00020000)
 #define WS_ENTER_ITEM(S_)                                                                         \
     do {                                                                                          \
         int b_, y0_, x0_, nb0_;                                                                   \
         decode(S_, b_, y0_, x0_, nb0_);                                                           \
-        const int row0_ = max(y0_ - 1, 0);                                                        \
-        rs0 = WS_MAKE_RS(0, b_, row0_);                                                           \
-        rs1 = WS_MAKE_RS(p.nseg > 1 ? 1 : 0, b_, row0_);                                          \
-        rs2 = WS_MAKE_RS(p.nseg > 2 ? 2 : 0, b_, row0_);                                          \
-        _Pragma("unroll") for (int k = 0; k < WS_PS; ++k) {                                       \
-            const int iy = y0_ - 1 + ppy[k], ix = x0_ - 1 + ppx[k];                               \
-            const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;                           \
-            ppix[k] = in ? (unsigned)((iy - row0_) * p.W + ix) : WOOB;                            \
+        l_border = y0_ < 1 || x0_ < 1 || y0_ + 9 > p.H || x0_ + 17 > p.W;                        \
+        const int row0_ = l_border ? max(y0_ - 1, 0) : y0_ - 1, col0_ = l_border ? 0 : x0_ - 1;   \
+        rs0 = WS_MAKE_RS(0, b_, row0_, col0_);                                                    \
+        rs1 = WS_MAKE_RS(p.nseg > 1 ? 1 : 0, b_, row0_, col0_);                                   \
+        rs2 = WS_MAKE_RS(p.nseg > 2 ? 2 : 0, b_, row0_, col0_);                                   \
+        if (l_border) {                                                                           \
+            _Pragma("unroll") for (int k = 0; k < WS_PS; ++k) {                                   \
+                const int iy = y0_ - 1 + ppy[k], ix = x0_ - 1 + ppx[k];                           \
+                const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;                       \
+                const unsigned pix = (unsigned)((iy - row0_) * p.W + ix);                         \
+                bv0[k] = in ? pix * (unsigned)sst40 + (unsigned)q4 * 4u : WOOB;                   \
+                bv1[k] = in ? pix * (unsigned)sst41 + (unsigned)q4 * 4u : WOOB;                   \
+                bv2[k] = in ? pix * (unsigned)sst42 + (unsigned)q4 * 4u : WOOB;                   \
+                bv0t[k] = q4 ? WOOB : bv0[k];                                                     \
+                bv1t[k] = q4 ? WOOB : bv1[k];                                                     \
+                bv2t[k] = q4 ? WOOB : bv2[k];                                                     \
+            }                                                                                     \
         }                                                                                         \
     } while (0)
-    // what the NEXT load instruction takes (WS_PREPARE, from the cursor): descriptor, scalar offset, per-slot byte offsets
-    __amdgpu_buffer_rsrc_t ld_rs;
-    int ld_soff;
-    unsigned ld_voff[WS_PS];
-#define WS_PREPARE()                                                                              \
-    do {                                                                                          \
-        const int scl_ = l_seg == 0 ? scl0 : (l_seg == 1 ? scl1 : scl2);                          \
-        const int sst4_ = l_seg == 0 ? sst40 : (l_seg == 1 ? sst41 : sst42);                      \
-        ld_rs = l_seg == 0 ? rs0 : (l_seg == 1 ? rs1 : rs2);                                      \
-        ld_soff = l_c0 * 4;                                                                       \
-        const bool qok_ = l_c0 + q4 < scl_;                                                       \
-        _Pragma("unroll") for (int k = 0; k < WS_PS; ++k)                                         \
-            ld_voff[k] = (qok_ && ppix[k] != WOOB) ? ppix[k] * (unsigned)sst4_ + (unsigned)q4 * 4u : WOOB; \
-    } while (0)
-// next chunk, next source, next item; past the last item the last chunk is fetched again (into a buffer nobody reads)
+// next chunk, next source, next item; past the last item the last chunk is fetched again (into a buffer nobody reads).  Scalar,
+// except for the vector work of WS_ENTER_ITEM on a border item.
 #define WS_ADVANCE()                                                                              \
     do {                                                                                          \
         const int sclc_ = l_seg == 0 ? scl0 : (l_seg == 1 ? scl1 : scl2);                         \
@@ -287,36 +328,33 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
             l_chunk = 0; l_seg = 0; l_c0 = 0;                                                     \
             WS_ENTER_ITEM(l_item);                                                                \
         }                                                                                         \
-        WS_PREPARE();                                                                             \
     } while (0)
     f32x4 prA[WS_PS] = {}, prB[WS_PS] = {};
-// no vector instruction in these three: the producer issues them while its SIMD's consumer streams MFMAs
+#define WS_LOAD2(PR, RS, VO)                                                                      \
+    do {                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < WS_PS; ++k)                                         \
+            PR[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RS, (int)VO[k], l_c0 * 4, 0)); \
+    } while (0)
+// the cursor's chunk -> PR: the register set of offsets is picked by scalar branches (source, tail chunk, border item)
 #define WS_LOADP(PR)                                                                              \
     do {                                                                                          \
-        if (!WS_DBG(1)) _Pragma("unroll") for (int k = 0; k < WS_PS; ++k)                         \
-            PR[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ld_rs, (int)ld_voff[k], ld_soff, 0)); \
+        if (!WS_DBG(1)) {                                                                         \
+            const int scl_ = l_seg == 0 ? scl0 : (l_seg == 1 ? scl1 : scl2);                      \
+            const bool tail_ = l_c0 + 4 >= scl_;                                                  \
+            if (!l_border) {                                                                      \
+                if (l_seg == 0) { if (tail_) WS_LOAD2(PR, rs0, iv0t); else WS_LOAD2(PR, rs0, iv0); } \
+                else if (l_seg == 1) { if (tail_) WS_LOAD2(PR, rs1, iv1t); else WS_LOAD2(PR, rs1, iv1); } \
+                else { if (tail_) WS_LOAD2(PR, rs2, iv2t); else WS_LOAD2(PR, rs2, iv2); }         \
+            } else {                                                                              \
+                if (l_seg == 0) { if (tail_) WS_LOAD2(PR, rs0, bv0t); else WS_LOAD2(PR, rs0, bv0); } \
+                else if (l_seg == 1) { if (tail_) WS_LOAD2(PR, rs1, bv1t); else WS_LOAD2(PR, rs1, bv1); } \
+                else { if (tail_) WS_LOAD2(PR, rs2, bv2t); else WS_LOAD2(PR, rs2, bv2); }         \
+            }                                                                                     \
+        }                                                                                         \
     } while (0)
 #define WS_COMMIT(PR, RSLOT)                                                                      \
     do {                                                                                          \
         _Pragma("unroll") for (int k = 0; k < WS_PS; ++k) smem4[(RSLOT)*WS_PBUF + plds[k]] = PR[k]; \
-    } while (0)
-#define WS_READRAW(RSLOT)                                                                         \
-    do {                                                                                          \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                           \
-            raw_[c] = smem4[(RSLOT)*WS_PBUF + abase + ((c >> 1) + (c & 1) * 9) * WPIXQ];          \
-            raw_[4 + c] = smem4[(RSLOT)*WS_PBUF + bbase + ((c >> 1) + (c & 1) * 9) * WPIXQ];      \
-        }                                                                                         \
-    } while (0)
-// V = (B^T d B)[pw][0..3] of the lane's (tile, k half) from raw_ -> V ring slot VSLOT (a run-time value: the first vector instruction)
-#define WS_XFORM(VSLOT)                                                                           \
-    do {                                                                                          \
-        f32x4 tt_[4];                                                                             \
-        f32x4 *vq_ = smem4 + vlane + (VSLOT)*1024;                                                \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) tt_[c] = sub4(raw_[c], raw_[4 + c], sb);    \
-        vq_[0 * 64] = sub4(tt_[0], tt_[2], m1);                                                   \
-        vq_[1 * 64] = tt_[1] + tt_[2];                                                            \
-        vq_[2 * 64] = sub4(tt_[2], tt_[1], m1);                                                   \
-        vq_[3 * 64] = sub4(tt_[1], tt_[3], m1);                                                   \
     } while (0)
 
     // row half of the output transform, bias, LeakyReLU and the stores of item s (its R planes are in the exchange area):
@@ -333,7 +371,7 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
             const int cb = (nb0 + nw) * 32 + 4 * g;
             f32x4 bias4[4];
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) bias4[rg] = *reinterpret_cast<const f32x4 *>(p.bias + cb + 8 * rg);
+            for (int rg = 0; rg < 4; ++rg) bias4[rg] = smem4[bias_q + ((cb + 8 * rg) >> 2)];
             float *orow = p.out + (size_t)((b * p.H + (ok ? oy : 0)) * p.W + (ok ? ox : 0)) * p.out_stride + cb;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
@@ -350,27 +388,19 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
         }
     };
 
-    // Producer step c, program order (PAR = c & 1 at compile time, so that every LDS address below is a register plus an immediate):
-    //   commit raw(c + 4) from the register set loaded two steps ago; fetch raw(c + 6) into it; read raw(c + 3) from LDS -- no vector
-    //   instruction so far: all of it issues beside the consumer's MFMAs -- then the vector section, which in practice runs when the
-    //   consumer has issued its last MFMA of the step and waits at the barrier (tools/micro/ws_gap.hip): the transform of raw(c + 3)
-    //   -> V(c + 3) (three-slot ring: the writes need not have landed before the NEXT barrier), the cursor and offsets of the next
-    //   load and, in the first step of an item, the previous item's output.
-    f32x4 raw_[8];
-    int vs3 = 0;                 // V slot of chunk c + 3 = (c + 3) mod 3
+    // Producer step c (PAR = c & 1 at compile time: the LDS addresses are registers plus immediates): commit raw(c + 2) from the
+    // register set loaded two steps ago, fetch raw(c + 4) into it, move the cursor.  In the first step of an item, the previous
+    // item's output (vector work: it runs when the consumers have issued that step's MFMAs and wait at the barrier).
     int cs = 0, cc = 0;          // the consumers' (item, chunk) of the current step
-#define WS_PSTEP(PAR, PR, FIRST, XF)                                                              \
+#define WS_PSTEP(PAR, PR, LEADIN)                                                                 \
     do {                                                                                          \
         WS_STAMP(d_a_);                                                                           \
         WS_COMMIT(PR, PAR);                                                                       \
         WS_STAMP(d_b_);                                                                           \
         WS_LOADP(PR);                                                                             \
-        if (XF) WS_READRAW((PAR) ^ 1);                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if ((XF) && !WS_DBG(32)) WS_XFORM(vs3);                                                   \
-        if (XF) vs3 = vs3 == 2 ? 0 : vs3 + 1;                                                     \
         WS_ADVANCE();                                                                             \
-        if (!(FIRST)) {                                                                           \
+        if (!(LEADIN)) {                                                                          \
             if (cc == 0 && cs > 0 && !WS_DBG(8)) finish_item(cs - 1);                             \
             if (++cc == nchunk) { cc = 0; ++cs; }                                                 \
         }                                                                                         \
@@ -378,19 +408,16 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
     } while (0)
 
     WS_ENTER_ITEM(0);
-    WS_PREPARE();
     WS_LOADP(prA);                     // raw(0)
     WS_ADVANCE();
     WS_LOADP(prB);                     // raw(1)
     WS_ADVANCE();
-    WS_PSTEP(0, prA, true, false);     // step -4: commit raw(0), fetch raw(2)
-    WS_PSTEP(1, prB, true, true);      // step -3: commit raw(1), fetch raw(3), raw(0) -> V(0)
-    WS_PSTEP(0, prA, true, true);      // step -2
-    WS_PSTEP(1, prB, true, true);      // step -1
+    WS_PSTEP(0, prA, true);            // step -2: commit raw(0), fetch raw(2)
+    WS_PSTEP(1, prB, true);            // step -1: commit raw(1), fetch raw(3)
     const int S = n_items * nchunk;
     for (int c = 0; c < S; c += 2) {
-        WS_PSTEP(0, prA, false, true);
-        if (c + 1 < S) WS_PSTEP(1, prB, false, true);
+        WS_PSTEP(0, prA, false);
+        if (c + 1 < S) WS_PSTEP(1, prB, false);
     }
     if (!WS_DBG(8)) finish_item(n_items - 1);
 #ifdef PIVLFN_STAMPS
@@ -401,12 +428,10 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
 #endif
 #undef WS_MAKE_RS
 #undef WS_ENTER_ITEM
-#undef WS_PREPARE
 #undef WS_ADVANCE
+#undef WS_LOAD2
 #undef WS_LOADP
 #undef WS_COMMIT
-#undef WS_READRAW
-#undef WS_XFORM
 #undef WS_PSTEP
 #undef WS_SYNC
 #undef WS_STAMP
@@ -416,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
 template <int NBW>
 static int launch_ws(const ConvParamsW &p, int grid, hipStream_t st)
 {
-    const size_t lds = (size_t)(WS_XQ + NBW * 2048) * 16;       // 133 KB (two channel blocks) / 100 KB
+    const size_t lds = (size_t)(WS_XQ + NBW * 2048) * 16 + (size_t)p.cout_pad * 4;       // 84 KB (two channel blocks) / 51 KB + the bias; the waves' registers keep it at one workgroup per CU
     static LdsAttr attr;
     if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_wino_ws_kernel<NBW>), (int)lds)) return rc;
     hipLaunchKernelGGL((conv_wino_ws_kernel<NBW>), dim3((unsigned)grid), dim3(512), lds, st, p);
@@ -429,6 +454,9 @@ long conv_wino_ws_items(const ConvParamsW &p)
 {
     const int nb = p.cout_pad / 32;
     if (p.nchunk < 2) return 0;
+    // the interior-item load offsets span 10 rows of a source: 32-bit byte offsets
+    for (int s = 0; s < p.nseg; ++s)
+        if ((long)10 * p.W * p.seg[s].stride * 4 >= (1L << 31)) return 0;
     const int nbw = nb % 2 == 0 ? 2 : 1;
     return (long)p.B * cdiv(p.H, 8) * cdiv(p.W, 16) * (nb / nbw);
 }
