@@ -278,8 +278,41 @@ def l3_throughput_regime(dev, batch=8, launches=40):
             "workload": f"level-3 warp+correlation of batch {batch} x 1024x1024 (C=64, stride 2, 2048 tiles), back-to-back launches"}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without an outer launcher: start N fresh ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, one device each), relay rank 0's output and return non-zero when a rank fails.  The parent makes no GPU call --
+    torch.cuda.device_count() does not initialise the device on this image -- and never re-executes itself."""
+    import socket
+    import subprocess
+    backend = os.environ.get("PIVLFN_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but {ndev} device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -394,7 +427,7 @@ def main():
             traffic, traffic_src = (counter_traffic("r04_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
                                     else (None, "no counter pass for this workload"))
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": f"{'warp_corr_v7_kernel (one tile per CU)' if (C % 64 == 0 and B * (S // (2 ** (L - 1)) // stride // 8) ** 2 <= 256) else 'warp_corr_v6_kernel (persistent)'} (level {L}: C={C}, stride {stride})",
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": f"{'warp_corr_v7_kernel (one tile per CU)' if (C % 64 == 0 and B * (S // (2 ** (L - 1)) // stride // 8) ** 2 <= torch.cuda.get_device_properties(dev).multi_processor_count) else 'warp_corr_v6_kernel (persistent)'} (level {L}: C={C}, stride {stride})",
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(t_k * 1e6, 2), "launches_timed": k_n,
                     "event_record_pair_us": round(t_pair * 1e6, 2),
                     "timer": "HIP start/stop events attached to the dispatch (hipExtLaunchKernelGGL) in every timed step, on the "

@@ -458,15 +458,11 @@ int launch_conv_w(const ConvParamsW &p_in, hipStream_t st)
     const int nb = p.cout_pad / 32;
     const long sp1 = (long)p.B * cdiv(p.H, 8) * cdiv(p.W, 16), sp2 = (long)p.B * cdiv(p.H, 16) * cdiv(p.W, 16);
     int mb = sp2 * nb >= 512 ? 2 : 1;
-    // From two work items per CU up the layer runs on persistent workgroups with producer / consumer waves (conv_wino_ws.hip):
-    // same values bit for bit, so this may follow the launch size and the batch.
-    const long ws_items = conv_wino_ws_items(p);
-    bool ws = ws_items >= 2L * device_cus();
 #ifdef PIVLFN_TOOLS
-    if (PIV_KNOB(14) == 30) ws = false;
-    if (PIV_KNOB(14) == 31) ws = ws_items > 0;
+    // Round 5's persistent kernel with specialised waves (conv_wino_ws.hip): same values bit for bit, 4-8 % slower than this kernel
+    // on every layer -- compiled into the tools library only, for A/B runs (knob 14 = 31).
+    if (PIV_KNOB(14) == 31 && conv_wino_ws_items(p) > 0) return launch_conv_w_ws(p, st);
 #endif
-    if (ws) return launch_conv_w_ws(p, st);
 #ifdef PIVLFN_TOOLS
     // A/B of the tile shapes (tools/bench_wino.py --masks): two or four channel blocks per wave halve / quarter the transform's
     // vector work per MFMA but run one workgroup per CU (16 accumulators) or spill (1 x 2): measured slower, see DESIGN.md

@@ -7,12 +7,15 @@
 // In conv_wino.hip every wave loads its share of the patch, commits it to LDS, transforms, multiplies and stores, and a workgroup
 // lives for one tile: of a launch's time 9 % is the patch traffic issued between the MFMAs and 11-30 % the workgroup's prologue
 // and epilogue.  Here:
-//   * One workgroup per CU (persistent, 512 threads).  Waves 0-3 -- one per SIMD -- are CONSUMERS: consumer i owns plane row i
-//     (planes (i, 0..3)) of a 32-tile x 32 NBW-channel work item, as a wave of conv_wino.hip does, and its K step is that kernel's
-//     without the staging: 16 NBW MFMAs, the raw operand reads of the NEXT chunk from LDS, its transform (16 packed instructions)
-//     and the weight fragments of the next chunk (buffer loads with scalar offsets behind each plane's MFMAs, into the registers that
-//     plane just read).
-//   * Waves 4-7 -- again one per SIMD -- are PRODUCERS: global -> registers -> LDS (two steps of latency cover, two register sets)
+//   * One workgroup per CU (persistent, 768 threads = three waves per SIMD).  Waves 0-7 -- two per SIMD -- are CONSUMERS: consumers i
+//     and 4 + i share plane row i of a 32-tile x 32 NBW-channel work item, planes (i, 0..1) and (i, 2..3).  A consumer's K step is a
+//     wave's of conv_wino.hip without the staging: 8 NBW MFMAs, the raw operand reads of the NEXT chunk from LDS (two patch rows x
+//     three columns), its share of the transform (10 packed instructions) and the weight fragments of the next chunk (buffer loads
+//     with scalar offsets behind each plane's MFMAs, into the registers that plane just read).  Two such waves per SIMD keep the
+//     matrix pipe fed the way two co-resident workgroups of conv_wino.hip do in their K loops: one wave's loads, waits and vector
+//     instructions are issued under the other's MFMAs (ONE consumer per SIMD pays every non-MFMA instruction in matrix time:
+//     round 5's second version, 0.68 of the peak).
+//   * Waves 8-11 -- one per SIMD -- are PRODUCERS: global -> registers -> LDS (two steps of latency cover, two register sets)
 //     for the raw-patch ring, and the stores.  Their steady state contains NO vector instruction: on this chip a vector instruction
 //     of the second wave of a SIMD is not executed beside a wave that streams fp32 MFMAs and meets it at barriers -- it waits until
 //     that wave pauses (tools/micro/ws_step.hip, ws_gap.hip: LDS writes, scalar work and loads of the second wave are free, its
@@ -37,13 +40,13 @@ constexpr int WS_PH = 10;                              // patch rows of an 8 x 4
 constexpr int WS_NSLOT = WS_PH * WPW * 2;              // 16-byte staging slots of one chunk's patch (360)
 constexpr int WS_PS = 2;                               // slots per producer thread
 constexpr int WS_PBUF = WS_PH * WROWQ + WPIXQ;         // quads per raw patch buffer (+ one spare record)
-constexpr int WS_XQ = 1152;                            // quad offset of the output-transform exchange (NBW x 2048 quads)
+constexpr int WS_XQ = 1152;                            // quad offset of the output-transform exchange (NBW x 4096 quads)
 static_assert(2 * WS_PBUF <= WS_XQ, "raw ring overlaps the exchange area");
 
 }  // namespace
 
 template <int NBW>
-__global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
+__global__ __launch_bounds__(768) void conv_wino_ws_kernel(const ConvParamsW p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4 *smem4 = reinterpret_cast<f32x4 *>(smem);
@@ -71,8 +74,8 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
     const int tid = threadIdx.x;
     // the layer's bias lives in LDS (behind the exchange area) for the life of the workgroup: the item's last step must not wait on
     // a global load that queues behind the patch loads in flight
-    const int bias_q = WS_XQ + NBW * 2048;
-    for (int i = tid; i < p.cout_pad; i += 512) smem[bias_q * 4 + i] = p.bias[i];
+    const int bias_q = WS_XQ + NBW * 4096;
+    for (int i = tid; i < p.cout_pad; i += 768) smem[bias_q * 4 + i] = p.bias[i];
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, g = lane >> 5;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
     // tools build: ablation mask p.dbg (1 no patch loads, 2 no weight refills, 4 no raw reads, 8 no finish_item, 16 no column half,
     // 32 no transform) and per-workgroup stamps of wave 0 (consumer) and wave 4 (producer): ticks spent waiting at the step barriers
     const int dbg = p.dbg;
-    const bool stamp_ = p.stamps != nullptr && (wave == 0 || wave == 4) && blockIdx.x < 4096;
+    const bool stamp_ = p.stamps != nullptr && (wave == 0 || wave == 8) && blockIdx.x < 4096;
     unsigned long long tk_ = 0, t_begin_ = 0, d_bar_ = 0, d_a_ = 0, d_b_ = 0;
     if (stamp_) t_begin_ = tk_ = __builtin_amdgcn_s_memtime();
 #define WS_STAMP(ACC)                                                                             \
@@ -115,22 +118,29 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
         b = t / tiles_y;
     };
 
-    if (wave < 4) {
-        // ------------------------------------------------------------------------------------------------ consumer, plane row `wave`
-        f32x16 acc[4][NBW];
+    if (wave < 8) {
+        // ------------------------------------------------------------------------------------ consumer: planes (pi, 2 ph) and (pi, 2 ph + 1)
+        const int pi = wave & 3, ph = wave >> 2;
+        f32x16 acc[2][NBW];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x4 V[4], Wt[NBW][4], raw[8] = {}, tt[4];
+        f32x4 V[2], Wt[NBW][2], rawa[3] = {}, rawb[3] = {}, tt[3];
         // weights of (chunk, block nb, plane row i): 4 planes x 64 lanes x 16 bytes, contiguous: byte offset ((chunk NB + nb) 4 + i) 4096
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wpk), 0,
                                                                             (unsigned)((size_t)nchunk * NB * 16 * 1024), 0x00020000);
-        const int wvoff = lane * 16;
+        const int wvoff = lane * 16 + ph * 2048;      // the wave's first plane inside the plane row's 4 KB
         const int wstep = NB * 4 * 4096;              // bytes from one chunk to the next
-        // plane row i = wave: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]
-        const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
-        const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
-        const float sb = wave == 1 ? 1.f : -1.f;
-        const int abase = (tyl + (ra >> 1) + (ra & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g;      // patch pixel (2 tyl + ra, 2 txl), in quads
-        const int bbase = (tyl + (rb >> 1) + (rb & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g;
+        // plane row i = pi: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]; this wave needs patch columns ph, ph + 1, ph + 2
+        const int ra = pi == 0 ? 0 : (pi == 2 ? 2 : 1);
+        const int rb = pi == 0 ? 2 : (pi == 1 ? 2 : (pi == 2 ? 1 : 3));
+        const float sb = pi == 1 ? 1.f : -1.f;
+        int aq[3], bq[3];                             // quad indices of the lane's six operands in raw slot 0
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = ph + k;
+            const int coff = ((c >> 1) + (c & 1) * 9) * WPIXQ;
+            aq[k] = (tyl + (ra >> 1) + (ra & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g + coff;      // patch pixel (2 tyl + ra, 2 txl + c)
+            bq[k] = (tyl + (rb >> 1) + (rb & 1) * (WS_PH / 2)) * WROWQ + txl * WPIXQ + g + coff;
+        }
 
 #define WS_MFMA(JP, Z)                                                                            \
     do {                                                                                          \
@@ -143,17 +153,24 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
         if (!WS_DBG(2)) _Pragma("unroll") for (int nw = 0; nw < NBW; ++nw)                        \
             Wt[nw][JP] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff + (JP)*1024, (SOFF) + nw * 16384, 0)); \
     } while (0)
-// the lane's 8 operand quads (rows ra, rb x columns 0..3 of its tile's patch) from the raw patch at quad offset RQ
+// the lane's 6 operand quads (rows ra, rb x three columns of its tile's patch) from the raw patch at quad offset RQ
 #define WS_READRAW(RQ)                                                                            \
     do {                                                                                          \
-        if (!WS_DBG(4)) _Pragma("unroll") for (int c = 0; c < 4; ++c) {                           \
-            raw[c] = smem4[(RQ) + abase + ((c >> 1) + (c & 1) * 9) * WPIXQ];                      \
-            raw[4 + c] = smem4[(RQ) + bbase + ((c >> 1) + (c & 1) * 9) * WPIXQ];                  \
+        if (!WS_DBG(4)) _Pragma("unroll") for (int k = 0; k < 3; ++k) {                           \
+            rawa[k] = smem4[(RQ) + aq[k]];                                                        \
+            rawb[k] = smem4[(RQ) + bq[k]];                                                        \
         }                                                                                         \
     } while (0)
-// One K step: chunk c's MFMAs plane by plane; behind plane jp's MFMAs the refill of that plane's weight registers with chunk c + 1
-// and a quarter of chunk c + 1's transform, V = (B^T d B)[wave][0..3] written in place (a plane's operand is dead once its MFMAs
-// are issued): raw reads behind plane 0, the row combination behind plane 1, columns 0-1 behind plane 2, columns 2-3 behind plane 3.
+// V = (B^T d B)[pi][2 ph .. 2 ph + 1] in place: row combination of the three columns, then planes 0, 1 from columns 0-2 or planes
+// 2, 3 from columns 1-3 (the same instructions on the same values as conv_wino.hip's WINO_XFORM)
+#define WS_XFORM()                                                                                \
+    do {                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) tt[k] = sub4(rawa[k], rawb[k], sb);         \
+        if (ph == 0) { V[0] = sub4(tt[0], tt[2], m1); V[1] = tt[1] + tt[2]; }                     \
+        else { V[0] = sub4(tt[1], tt[0], m1); V[1] = sub4(tt[0], tt[2], m1); }                    \
+    } while (0)
+// One K step: chunk c's MFMAs, plane by plane; behind a plane's MFMAs the refill of its weight registers with chunk c + 1; the raw
+// reads of chunk c + 1 behind the first plane, its transform (in place: a plane's operand is dead once its MFMAs are issued) last.
 #define WS_CSTEP(Z, RQ, SOFF)                                                                     \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
@@ -165,35 +182,20 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
         WS_MFMA(1, Z);                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WS_REFILLW(1, SOFF);                                                                      \
-        if (!WS_DBG(32)) _Pragma("unroll") for (int c = 0; c < 4; ++c) tt[c] = sub4(raw[c], raw[4 + c], sb); \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        WS_MFMA(2, Z);                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        WS_REFILLW(2, SOFF);                                                                      \
-        if (!WS_DBG(32)) { V[0] = sub4(tt[0], tt[2], m1); V[1] = tt[1] + tt[2]; }                 \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        WS_MFMA(3, Z);                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        WS_REFILLW(3, SOFF);                                                                      \
-        if (!WS_DBG(32)) { V[2] = sub4(tt[2], tt[1], m1); V[3] = sub4(tt[1], tt[3], m1); }        \
+        if (!WS_DBG(32)) WS_XFORM();                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
 
         auto item_woff = [&](int s) {
             const int t = t0 + s * tstep;
-            return (((t % NG) * NBW) * 4 + wave) * 4096;
+            return (((t % NG) * NBW) * 4 + pi) * 4096;
         };
         int woff = item_woff(0);
 #pragma unroll
-        for (int jp = 0; jp < 4; ++jp) WS_REFILLW(jp, woff);
+        for (int jp = 0; jp < 2; ++jp) WS_REFILLW(jp, woff);
         WS_SYNC();      // step -2: raw(0) committed
         WS_READRAW(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tt[c] = sub4(raw[c], raw[4 + c], sb);
-        V[0] = sub4(tt[0], tt[2], m1);
-        V[1] = tt[1] + tt[2];
-        V[2] = sub4(tt[2], tt[1], m1);
-        V[3] = sub4(tt[1], tt[3], m1);
+        WS_XFORM();
         WS_SYNC();      // step -1: raw(1) committed
         int rq = WS_PBUF;     // quad offset of the raw slot the next step reads (chunk c + 1)
         for (int s = 0; s < n_items; ++s) {
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
             // last chunk: the refills and the transform are those of the next item's first chunk (past the end: nobody uses them)
             soff = more ? woff_next : soff;
             WS_CSTEP(false, rq, soff);
-            // column half of the output transform: R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 -> LDS [nw][plane row][q][rg][lane]
+            // column half of the output transform, R[0] = (M0 + M1) + M2 and R[1] = (M1 - M2) - M3, split over the two waves of the
+            // plane row: this wave leaves (M0 + M1, M1) or (M2, M3) in LDS [nw][plane row][ph][2][rg][lane]; the producers finish it
             f32x4 *xch = smem4 + WS_XQ;
             WS_STAMP(d_a_);
             if (!WS_DBG(16))
@@ -220,12 +223,12 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
             for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    f32x4 m[4];
+                    f32x4 m[2];
 #pragma unroll
-                    for (int jp = 0; jp < 4; ++jp)
+                    for (int jp = 0; jp < 2; ++jp)
                         m[jp] = f32x4{acc[jp][nw][4 * rg + 0], acc[jp][nw][4 * rg + 1], acc[jp][nw][4 * rg + 2], acc[jp][nw][4 * rg + 3]};
-                    xch[(((nw * 4 + wave) * 2 + 0) * 4 + rg) * 64 + lane] = (m[0] + m[1]) + m[2];
-                    xch[(((nw * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = sub4(sub4(m[1], m[2], m1), m[3], m1);
+                    xch[((((nw * 4 + pi) * 2 + ph) * 2 + 0) * 4 + rg) * 64 + lane] = ph == 0 ? m[0] + m[1] : m[0];
+                    xch[((((nw * 4 + pi) * 2 + ph) * 2 + 1) * 4 + rg) * 64 + lane] = m[1];
                 }
             WS_STAMP(d_b_);
             WS_SYNC();
@@ -242,12 +245,13 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
 #undef WS_MFMA
 #undef WS_REFILLW
 #undef WS_READRAW
+#undef WS_XFORM
         return;
     }
 
     // ---------------------------------------------------------------------------------------------------- producer
-    const int pw = wave - 4;
-    const int ptid = tid - 256;
+    const int pw = wave - 8;
+    const int ptid = tid - 512;
     // staging slots of this thread: slot k covers (pixel, quad) = (idx >> 1, idx & 1), idx = ptid + 256 k (conv_wino.hip)
     int plds[WS_PS], ppy[WS_PS], ppx[WS_PS];
     const int q4 = (ptid & 1) * 4;
@@ -357,33 +361,53 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
         _Pragma("unroll") for (int k = 0; k < WS_PS; ++k) smem4[(RSLOT)*WS_PBUF + plds[k]] = PR[k]; \
     } while (0)
 
-    // row half of the output transform, bias, LeakyReLU and the stores of item s (its R planes are in the exchange area):
-    // producer wave pw finishes output pixel (pp, qq) of every tile
+    // The rest of the output transform of item s, whose planes are in the exchange area: producer wave pw finishes output pixel
+    // (pp, qq) of every tile -- column half R[qq] of three plane rows from the consumers' halves, row half, bias, LeakyReLU, stores.
+    // All LDS reads of a channel block are issued first (no vector instruction in front of them: they travel while the consumers
+    // still multiply); the arithmetic runs when the consumers wait at the step's barrier.
     auto finish_item = [&](int s) {
         int b, y0, x0, nb0;
         decode(s, b, y0, x0, nb0);
         const int pp = pw >> 1, qq = pw & 1;
-        const f32x4 *xch = smem4 + WS_XQ;
+        const f32x4 *xch = smem4 + WS_XQ + lane;
         const int oy = y0 + 2 * tyl + pp, ox = x0 + 2 * txl + qq;
         const bool ok = oy < p.H && ox < p.W;
 #pragma unroll
         for (int nw = 0; nw < NBW; ++nw) {
             const int cb = (nb0 + nw) * 32 + 4 * g;
-            f32x4 bias4[4];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) bias4[rg] = smem4[bias_q + ((cb + 8 * rg) >> 2)];
             float *orow = p.out + (size_t)((b * p.H + (ok ? oy : 0)) * p.W + (ok ? ox : 0)) * p.out_stride + cb;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const f32x4 *x = xch + (((nw * 4) * 2 + qq) * 4 + rg) * 64 + lane;     // plane row i at x[i * 512]
-                f32x4 y;
-                if (pp == 0) y = (x[0] + x[1 * 512]) + x[2 * 512];
-                else y = sub4(sub4(x[1 * 512], x[2 * 512], m1), x[3 * 512], m1);
-                y += bias4[rg];
-                if (p.lrelu) {
-                    y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
+            for (int rh = 0; rh < 4; ++rh) {
+                // kinds: [ph 0][0] = M0 + M1, [ph 0][1] = M1, [ph 1][0] = M2, [ph 1][1] = M3 of plane row i at ((nw 4 + i) 4 + kind) 256 + rg 64
+                f32x4 in[1][3][3], bias4[1];
+#pragma unroll
+                for (int r2 = 0; r2 < 1; ++r2) {
+                    const int rg = rh + r2;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const f32x4 *x = xch + ((nw * 4 + pp + r) * 4) * 256 + rg * 64;
+                        if (qq == 0) { in[r2][r][0] = x[0 * 256]; in[r2][r][1] = x[2 * 256]; }
+                        else { in[r2][r][0] = x[1 * 256]; in[r2][r][1] = x[2 * 256]; in[r2][r][2] = x[3 * 256]; }
+                    }
+                    bias4[r2] = smem4[bias_q + ((cb + 8 * rg) >> 2)];
                 }
-                if (ok && cb + 8 * rg < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * rg) = y;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r2 = 0; r2 < 1; ++r2) {
+                    const int rg = rh + r2;
+                    f32x4 R[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        R[r] = qq == 0 ? in[r2][r][0] + in[r2][r][1] : sub4(sub4(in[r2][r][0], in[r2][r][1], m1), in[r2][r][2], m1);
+                    f32x4 y;
+                    if (pp == 0) y = (R[0] + R[1]) + R[2];
+                    else y = sub4(sub4(R[0], R[1], m1), R[2], m1);
+                    y += bias4[r2];
+                    if (p.lrelu) {
+                        y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
+                    }
+                    if (ok && cb + 8 * rg < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * rg) = y;
+                }
             }
         }
     };
@@ -441,10 +465,10 @@ __global__ __launch_bounds__(512) void conv_wino_ws_kernel(const ConvParamsW p)
 template <int NBW>
 static int launch_ws(const ConvParamsW &p, int grid, hipStream_t st)
 {
-    const size_t lds = (size_t)(WS_XQ + NBW * 2048) * 16 + (size_t)p.cout_pad * 4;       // 84 KB (two channel blocks) / 51 KB + the bias; the waves' registers keep it at one workgroup per CU
+    const size_t lds = (size_t)(WS_XQ + NBW * 4096) * 16 + (size_t)p.cout_pad * 4;       // 146 KB (two channel blocks) / 82 KB + the bias: one workgroup per CU
     static LdsAttr attr;
     if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(conv_wino_ws_kernel<NBW>), (int)lds)) return rc;
-    hipLaunchKernelGGL((conv_wino_ws_kernel<NBW>), dim3((unsigned)grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv_wino_ws_kernel<NBW>), dim3((unsigned)grid), dim3(768), lds, st, p);
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }

@@ -80,6 +80,8 @@ struct pivlfn_net {
     pivlfn::ConvW ext[3];          // index by level (1,2)
     pivlfn::LevelW lv[7];
     std::vector<void *> allocs;
+    bool pack_w4 = false;          // also pack the F(4x4, 3x3) Winograd weights of 3 x 3 layers: the owner of a stand-alone layer object
+                                   // (pivlfn_conv2d_nhwc_wino4 needs them); a network never launches that kernel
     // side stream for the flow-independent 1x1 convs (NetC_ext, moduleFeat): they overlap the latency-bound coarse levels
     hipStream_t side = nullptr;
     float *fuse1_w = nullptr, *fuse1_b = nullptr;      // level 1: NetC_ext + moduleFeat as 1 x 1 layers inside NetC.conv1's kernel (Conv1Fuse)
@@ -215,9 +217,18 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         pack_conv_w(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w);
         rc = upload(net, pw, &out->wpk_w);
         if (rc) return rc;
-        pack_conv_w4(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w4);
-        rc = upload(net, pw, &out->wpk_w4);
-        if (rc) return rc;
+        // F(4x4): 2.25 x the F(2x2) planes per layer -- only where something can launch it (round 4 packed and uploaded it for every
+        // 3 x 3 layer of every network although pivlfn_forward never reaches that kernel outside the tools build's knob 13)
+#ifdef PIVLFN_TOOLS
+        const bool w4 = true;
+#else
+        const bool w4 = net->pack_w4;
+#endif
+        if (w4) {
+            pack_conv_w4(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w4);
+            rc = upload(net, pw, &out->wpk_w4);
+            if (rc) return rc;
+        }
     }
     if (conv_split_supports(kh, kw, 1, cp, 6)) {   // the split-operand packing of the same layer (fp32 on the fp16 matrix cores)
         std::vector<int> cr, cl, co;
@@ -470,6 +481,7 @@ int conv_create(const float *weight, const float *bias, int cout, int cin, int k
     m["c.bias"] = &t[1];
     pivlfn_conv *c = new pivlfn_conv();
     c->owner = new pivlfn_net();
+    c->owner->pack_w4 = true;
     c->cin = cin;
     int rc = pack_conv(c->owner, m, "c", cout, cin, kh, kw, {{cin, rup(cin, 4)}}, &c->cw);
     if (!rc && cout == 2 && cin == 32 && kh == kw && (kh == 3 || kh == 5 || kh == 7)) rc = pack_head(c->owner, m, "c", kh, &c->head, c->hb);
@@ -822,6 +834,7 @@ int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     q.cout_pad = c->cw.cout_pad;
     q.B = B; q.H = H; q.W = W; q.nchunk = c->cw.nchunk_w; q.lrelu = leaky;
     if (tile == 4) {
+        PIV_REQUIRE(c->cw.wpk_w4, "conv2d_wino4: the layer object carries no F(4x4) weights");
         q.wpk = c->cw.wpk_w4; q.nchunk = c->cw.nchunk_w4;
         return launch_conv_w4(q, st);
     }

@@ -828,7 +828,7 @@ static int launch_wc(const WcParams &p, hipStream_t st)
 //                (100 KB per CU), rolling: wait for the oldest item, blend, store to LDS, issue the same item of the NEXT chunk
 //                (or of the next tile: its taps are computed from a flow value fetched one phase ahead) -- the CU's load path
 //                never drains, across chunk and tile boundaries alike; they also store the previous tile's output rows.
-//   wave  7      helper: the f1 tile (8 loads per lane) and the 4 left-over positions 192..195.
+//   wave  7      helper: the f1 tile (8 loads per lane); the 4 left-over positions 192..195 are the producers' item u = 3.
 //   waves 0..6   consumers: wave = displacement column dx; lane = (row half h, column j, channel quad g); a lane owns the 4
 //                output rows of its half at column j and one 16-byte quad of a 16-channel plane.  One ds_read_b128 of the warped
 //                tile at row r feeds the displacements dy = r - yy of all four rows: 14 reads per 112 fused multiply-adds
@@ -928,10 +928,15 @@ __device__ __forceinline__ void k6_taps(const WcParams &p, unsigned pix_bytes, i
     }
 }
 
-__device__ __forceinline__ float2 k6_flow(const WcParams &p, __amdgpu_buffer_rsrc_t rsf, int b, int iy, int ix)
+// the flow of image b through a descriptor of that image alone (scalar arithmetic per call: only one image's flow, 16 bytes per
+// pixel, has to fit the descriptor's 2 GiB -- a descriptor over the whole batch refused B >= 128 at 1024 x 1024)
+__device__ __forceinline__ float2 k6_flow(const WcParams &p, int b, int iy, int ix)
 {
+    const size_t img = (size_t)p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.flow ? p.flow + (size_t)b * img * 4 : p.f1), 0,
+                                                                         p.flow ? (unsigned)(img * 16) : 0u, 0x00020000);
     const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    const unsigned off = in ? (unsigned)((b * p.H + iy) * p.W + ix) * 16u : OOB;
+    const unsigned off = in ? (unsigned)(iy * p.W + ix) * 16u : OOB;
     return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsf, (int)off, 0, 0));
 }
 
@@ -1121,9 +1126,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
         return;
     }
 
-    // descriptors: flow of the whole batch (offsets carry the image), features per image
-    const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.flow ? p.flow : p.f1), 0,
-                                                                         p.flow ? (unsigned)((size_t)p.B * img * 16) : 0u, 0x00020000);
+    // descriptors: flow, features and output per image (made where the image is known)
     K6Iter cur = k6_begin(S);
     K6Tile T = k6_tile(S, cur);
 
@@ -1196,19 +1199,21 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
     f32x4 x[NS][NT];
     unsigned dst[NS], tof[NS];                       // per item: LDS destination (buffer-relative) and tap-table entry of this unit
     float2 fl = {0.f, 0.f};
-    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((size_t)p.B * p.Ho * p.Wo * OUTC * 4), 0x00020000);
     auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
     // Output rows of tile t from the LDS image: 896 quads over 512 lanes, as buffer stores whose offset is out of range for lanes
     // (or phases: `on`) with nothing to store -- no branch, so the counted waits of the phase stay counted.
     auto store_tile = [&](int tpl, const K6Tile &t, bool on) {
         const float *tr = reinterpret_cast<const float *>(lds + K6_TR);
+        // the output of the tile's image alone (scalar arithmetic per tile): one image's 56 lanes have to fit 2 GiB, not the batch's
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)t.b * p.Ho * p.Wo * OUTC, 0,
+                                                                             (unsigned)((size_t)p.Ho * p.Wo * OUTC * 4), 0x00020000);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int item = min(tpl + 512 * u, 64 * (OUTC / 4) - 1);
             const int px = item / (OUTC / 4), q = item - px * (OUTC / 4);
             const int oy = t.oy0 + (px >> 3), ox = t.ox0 + (px & 7);
             const bool ok = on & (tpl + 512 * u < 64 * (OUTC / 4)) & (oy < p.Ho) & (ox < p.Wo) & !(p.dbg & 4);      // & not &&: no short-circuit branches
-            const unsigned off = ok ? (unsigned)(((t.b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) * 4u : OOB;
+            const unsigned off = ok ? (unsigned)((oy * p.Wo + ox) * OUTC + 4 * q) * 4u : OOB;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + px * OUTC + 4 * q);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rso, (int)off, 0, 0);
         }
@@ -1231,7 +1236,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
     auto tap_pos = [&](const K6Tile &t) { return pos_base(t) + 64 * ((lane & (8 * NS - 1)) >> 3) + 8 * wp + (lane & 7); };
     auto tap_flow = [&](const K6Tile &t) {
         const int pos = min(tap_pos(t), NPOS - 1);
-        return k6_flow(p, rsf, t.b, (t.oy0 + pos / TP - 3) * p.s, (t.ox0 + pos % TP - 3) * p.s);
+        return k6_flow(p, t.b, (t.oy0 + pos / TP - 3) * p.s, (t.ox0 + pos % TP - 3) * p.s);
     };
     auto tap_write = [&](const K6Tile &t, float2 uv) {
         const int pos = tap_pos(t), pp = min(pos, NPOS - 1);
@@ -1346,8 +1351,9 @@ template <bool HASFLOW>
 static int launch_wc6(WcParams p, hipStream_t st)
 {
     PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
-    PIV_REQUIRE((size_t)p.B * p.H * p.W * 16 < 0x7fffffffull, "warp_corr: the flow of %d x %dx%d exceeds the 2 GiB buffer-descriptor range", p.B, p.H, p.W);
-    PIV_REQUIRE((size_t)p.B * p.Ho * p.Wo * OUTC * 4 < 0x7fffffffull, "warp_corr: the output of %d x %dx%d exceeds the 2 GiB buffer-descriptor range", p.B, p.Ho, p.Wo);
+    // flow and output go through per-image descriptors too: no limit on the batch (round 4 refused B >= 37 at level 1 of 1024 x 1024 pairs)
+    PIV_REQUIRE((size_t)p.H * p.W * 16 < 0x7fffffffull && (size_t)p.Ho * p.Wo * OUTC * 4 < 0x7fffffffull,
+                "warp_corr: the flow or the output of one %dx%d image exceeds the 2 GiB buffer-descriptor range", p.H, p.W);
     const int tiles_x = cdiv(p.Wo, TO), tiles_y = cdiv(p.Ho, TO);
     const int slots = std::max(8, device_cus() / 8 * 8);          // one 16-wave workgroup per CU; a multiple of 8 keeps the XCD bands
     // Run length: the sliding window needs chunk k of every tile in buffer k (two chunks: C = 64).  The longest power-of-two run
@@ -1409,8 +1415,6 @@ __global__ __launch_bounds__(1024) void warp_corr_v7_kernel(const WcParams p)
     const unsigned pix_bytes = (unsigned)p.C * 4u;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f1 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.f2 + (size_t)b * img * p.C), 0, img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.flow ? p.flow : p.f1), 0,
-                                                                         p.flow ? (unsigned)((size_t)p.B * img * 16) : 0u, 0x00020000);
 
     // f1: threads 0..511 own (row pair rp, column, quad): rows 2 rp and 2 rp + 1 of the tile -- independent of the flow, issued first
     const int q16 = tid & 15;
@@ -1427,7 +1431,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v7_kernel(const WcParams p)
         const int pos = 64 * (l16 >> 2) + 4 * wave + (l16 & 3), pp = min(pos, NPOS - 1);
         const int iy = (oy0 + pp / TP - 3) * p.s, ix = (ox0 + pp % TP - 3) * p.s;
         float2 uv = {0.f, 0.f};
-        if (HASFLOW) uv = k6_flow(p, rsf, b, iy, ix);
+        if (HASFLOW) uv = k6_flow(p, b, iy, ix);
         i32x4 o; f32x4 w;
         k6_taps<HASFLOW>(p, pix_bytes, iy, ix, uv, o, w);
         if (pos < NPOS) {
@@ -1528,7 +1532,7 @@ template <bool HASFLOW>
 static int launch_wc7(const WcParams &p, hipStream_t st)
 {
     PIV_REQUIRE((size_t)p.H * p.W * p.C * sizeof(float) < 0x7fffffffull, "warp_corr: one image of %dx%dx%d exceeds the 2 GiB buffer-descriptor range", p.H, p.W, p.C);
-    PIV_REQUIRE((size_t)p.B * p.H * p.W * 16 < 0x7fffffffull, "warp_corr: the flow of %d x %dx%d exceeds the 2 GiB buffer-descriptor range", p.B, p.H, p.W);
+    PIV_REQUIRE((size_t)p.H * p.W * 16 < 0x7fffffffull, "warp_corr: the flow of one %dx%d image exceeds the 2 GiB buffer-descriptor range", p.H, p.W);
     static LdsAttr attr;
     const int ldsb = (K7_LDS + 255) / 256 * 256;
     if (int rc = ensure_dyn_lds(attr, reinterpret_cast<const void *>(warp_corr_v7_kernel<HASFLOW>), ldsb)) return rc;

@@ -202,6 +202,24 @@ def test_bench_py_two_rank_rehearsal(dev):
     assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01                  # value = all ranks' pairs / max time
 
 
+def test_bench_py_starts_its_own_ranks(dev):
+    """The plain command `python bench.py --gpus 2` with no outer launcher and no RANK / WORLD_SIZE in the environment: the parent
+    starts two fresh ranks itself (gloo here: one GPU) and relays rank 0's single JSON line; asking for more devices than are
+    visible with the RCCL backend is refused before anything is started."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256", "--no-cpu-baseline",
+           "--no-arithmetic", "--lean"]
+    r = subprocess.run(cmd, env=dict(env, PIVLFN_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and "metric" in ln]
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 2 and len(j["per_rank"]) == 2 and j["value"] > 0
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=dict(env, PIVLFN_BENCH_BACKEND="nccl"), capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "device(s) visible" in r.stderr and not r.stdout.strip()
+
+
 def test_rccl_branch_executes_on_one_rank(dev, tmp_path):
     """The `nccl` (= RCCL) code paths, which the gloo rehearsals replace, executed for real in a fresh child with a process group
     of one rank on this one GPU: bench.py's init_process_group("nccl", device_id=...) + asynchronous all_gather_into_tensor +

@@ -75,7 +75,8 @@ def test_wino_matches_float64_conv(case, dev):
 
 @pytest.mark.parametrize("case", CASES)
 def test_wino4_matches_float64_conv(case, dev):
-    """The F(4x4, 3x3) kernel (csrc/conv_wino4.hip; levels 1 and 2 of a 1024 x 1024 pair in the default mode) on the same shapes:
+    """The F(4x4, 3x3) kernel (csrc/conv_wino4.hip: an entry point of its own, pivlfn_conv2d_nhwc_wino4 -- pivlfn_forward never
+    launches it) on the same shapes:
     its transforms multiply by 2, 4, 5 and 8, so a layer's error against float64 is ~8e-6 of max |out| where F(2x2) and the direct
     kernel stay below 5e-7 (measured on the CPU restatement before the kernel existed: DESIGN.md 4.2c); the per-layer bound here is
     3e-5, and what decides is the end-to-end bound every oracle test holds the network to (1e-4 of the flow scale)."""

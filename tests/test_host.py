@@ -220,3 +220,18 @@ def test_no_kernel_spills_to_scratch():
                         limit = max([v for k, v in allowed.items() if k in name] + [0])
                         assert n <= limit, f"{name} spills {n} registers to scratch"
     assert seen > 50          # every kernel of the library was looked at
+
+
+def test_bench_py_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus 8` with no outer launcher starts its own ranks; with fewer devices visible than ranks asked for (none
+    in this container) the parent refuses before it starts anything and before it touches a GPU itself."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PIVLFN_BENCH_BACKEND")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("eight devices are visible here")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "device(s) visible" in r.stderr and not r.stdout.strip()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counters of the separable distance convolutions (conv_col7 / conv_row7, 1024 x 1024): matrix-pipe busy cycles, wave waits,
-# instruction counts.  One rocprofv3 --pmc pass (no other trace domains).  bash tools/pmc_dist.sh -> gpurun_out/pmc_dist/
+# instruction counts.  One rocprofv3 --pmc pass (with --kernel-trace for the per-dispatch rows; none of the hip / hsa / memory-copy / marker domains).  bash tools/pmc_dist.sh -> gpurun_out/pmc_dist/
 set -e
 OUT=$PWD/gpurun_out/pmc_dist
 mkdir -p "$OUT"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counters of NetC's dedicated kernels inside the forward (conv_c3k7<true>: conv1 + the level-1 1 x 1 layers; conv_s2c32: the stride-2
-# layers from 32 channels): matrix-pipe busy cycles, waits, HBM bytes.  Separate rocprofv3 --pmc passes (no other trace domains).
+# layers from 32 channels): matrix-pipe busy cycles, waits, HBM bytes.  Separate rocprofv3 --pmc passes (with --kernel-trace for the per-dispatch rows; none of the hip / hsa / memory-copy / marker domains).
 #   bash tools/pmc_netc.sh -> gpurun_out/pmc_netc/
 set -e
 OUT=$PWD/gpurun_out/pmc_netc
