@@ -1,7 +1,12 @@
 // Which instructions of the second wave of a SIMD stall until its partner's v_mfma_f32_32x32x2_f32 stream pauses?
 // One 512-thread workgroup per CU, no barriers: waves 0-3 issue blocks of NM back-to-back MFMAs (one scalar loop branch between
 // blocks), waves 4-7 run `iters` iterations of a probe: 16 independent v_fma_f32 plus ONE instruction of the kind under test.
-// Reported: cycles per probe iteration alone (MFMA waves idle) and beside the MFMA stream, for MFMA blocks of 8, 32 and 128.
+// Reported: cycles per probe iteration alone (MFMA waves idle) and beside the MFMA stream, for MFMA blocks of 8, 32 and 128, gapless
+// or with one / three `s_nop 15` (64 cycles each) behind every MFMA; for the plain probe also the VGPR base of each wave (the
+// starvation is not a matter of where the registers were allocated).
+// What it shows (round 5): beside a gapless stream the probe usually keeps its pace (the mfma_neighbour result) -- but not in every
+// launch; with ONE s_nop 15 behind each MFMA (the wave asks for nothing for 64 of every 68 cycles) the probe does not run at all
+// until the stream ends; with three (matrix pipe idle two thirds of the time) it runs at 1.5 x its time alone.
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/ws_stall.hip -o tools/micro/ws_stall && tools/micro/ws_stall
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -152,9 +157,8 @@ int main()
     (void)hipMalloc(&ticks, 2 * 256 * 8 * 8);
     (void)hipMemset(src, 0, 1 << 20);
     run3<0>(src, dst, ticks, "nothing else");
+    run3<0>(src, dst, ticks, "nothing else");           // three times: which launches starve the probe is not a property of the code
     run3<0>(src, dst, ticks, "nothing else");
-    run3<0>(src, dst, ticks, "nothing else");
-    return 0;
     run3<1>(src, dst, ticks, "v_cmp -> SGPR, scalar reader");
     run3<11>(src, dst, ticks, "v_cmp -> SGPR, v_cndmask reader");
     run3<2>(src, dst, ticks, "v_cmp -> VCC, v_cndmask reader");
