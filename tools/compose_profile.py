@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """profiles/rNN_a_kernel_stats.md from what tools/profile_round.sh left under gpurun_out/rNN: the stats table, the level-3 / level-1
-warp+correlation launches of the trace, the per-level timeline and the un-profiled bench line.   python tools/compose_profile.py r04"""
+warp+correlation launches of the trace, the per-level timeline and the un-profiled bench line.   python tools/compose_profile.py r05"""
 import csv
 import glob
 import subprocess
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 R = f"gpurun_out/{rnd}"
 commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
 stats = open(f"{R}/kernel_stats_fp32.md").read()

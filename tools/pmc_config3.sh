@@ -1,7 +1,7 @@
 #!/bin/bash
 # BASELINE config #3 (batch 32 x 512x512): counter passes on the level-3 warp+correlation launch of that workload (128x128
 # features, stride 2, 64 channels, 2048 tiles), each counter group in its own rocprofv3 --pmc run.  From the repo root on the
-# GPU box:  bash tools/pmc_config3.sh  -> gpurun_out/pmc_config3/r04_pmc_config3.json   (needs the tools build for bench_ops.py)
+# GPU box:  bash tools/pmc_config3.sh  -> gpurun_out/pmc_config3/r05_pmc_config3.json   (needs the tools build for bench_ops.py)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_config3

@@ -18,24 +18,14 @@ C, n, s = {1: (64, 1024, 2), 2: (64, 512, 2), 3: (64, 256, 2)}[level]
 tiles = (n // s // 8) ** 2 * batch
 
 
-def counters(tag):
-    """Counter values of the level's launches.  Round 4: the kernels are persistent (the grid no longer tells the level), so
-    the launches are picked by position: a lean bench run consists of forwards only and a forward launches warp+correlation for
-    levels 6, 5, 4, 3, 2, 1 in that order (dispatch k of the process -> level 6 - k % 6); the batch-8 figures come from a
-    process that launches nothing else (tools/wc_standalone.py), its first two launches dropped as warm-up."""
-    rows = []
-    sub = ("b8_" if batch == 8 else "net_") + tag
-    for path in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
-        rows += [r for r in csv.DictReader(open(path)) if "warp_corr" in r["Kernel_Name"]]
-    by_disp = {}
-    for r in rows:
-        by_disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
-    ids = sorted(by_disp)
-    if batch == 8:
-        pick = ids[2:]
-    else:
-        assert len(ids) % 6 == 0, f"{len(ids)} warp+correlation dispatches: not a whole number of forwards"
-        pick = [d for k, d in enumerate(ids) if 6 - k % 6 == level][1:]          # the first forward is the warm-up
+# what each figure's launch must be (fails loudly when the launch policy, the forward or the profiled process changes)
+EXPECT = {(3, 1): "warp_corr_v7_kernel<true>", (1, 1): "warp_corr_v6_kernel<true, 2>", (2, 1): "warp_corr_v6_kernel<true, 2>", (3, 8): "warp_corr_v6_kernel<true, 2>"}
+
+
+def pick_dispatches(rows):
+    """Dispatch ids of the level's launches among the warp+correlation rows of one profiled process, by position -- and checked
+    against the kernel the launch policy picks for that shape."""
+    by_disp, pick = pick_dispatches(rows)
     vals = {}
     for d in pick:
         for r in by_disp[d]:
@@ -55,6 +45,7 @@ for rel in ("piv_liteflownet-pytorch_amd/csrc/warp_corr.hip", "piv_liteflownet-p
     h.update(open(os.path.join(ROOT, rel), "rb").read())
 no = n // s
 alg = 4 * (C * no * no + C * n * n + 2 * n * n + 49 * no * no) * batch
+trace_us, trace_n = trace_duration_us()
 print(json.dumps({
     "kernel": f"{res.get('_kernel', '?')} (level {level} of PIV 1024x1024 B={batch}: C={C}, stride {s}, {tiles} tiles)",
     "launches_averaged": len(res.get("FETCH_SIZE", {})),
@@ -63,6 +54,8 @@ print(json.dumps({
     "hbm_bytes_per_launch": int(round((2 * fetch_kb + write_kb) * 1024)),
     "algorithmic_bytes_per_launch": alg,
     "TCC_HIT_sum": mean(res.get("TCC_HIT_sum", {})), "TCC_MISS_sum": mean(res.get("TCC_MISS_sum", {})),
+    "rocprofv3_kernel_trace_avg_us": None if trace_us is None else round(trace_us, 2), "kernel_trace_launches_averaged": trace_n,
+    "roofline_frac_from_kernel_trace": None if trace_us is None else round(alg / (trace_us * 1e-6) / 8e12, 4),
     "kernel_source_sha256_16": h.hexdigest()[:16],
     "passes": "three separate rocprofv3 --pmc runs (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-level 0 --no-arithmetic --lean` (batch 1, launches picked by position in the forward) or of `tools/wc_standalone.py --level 3 --batch 8` (batch 8), tools/pmc_l3.sh",
 }, indent=1))
