@@ -23,8 +23,45 @@ EXPECT = {(3, 1): "warp_corr_v7_kernel<true>", (1, 1): "warp_corr_v6_kernel<true
 
 
 def pick_dispatches(rows):
-    """Dispatch ids of the level's launches among the warp+correlation rows of one profiled process, by position -- and checked
-    against the kernel the launch policy picks for that shape."""
+    """Dispatch ids of the level's launches among the warp+correlation rows of one profiled process, by position -- a lean bench
+    run consists of forwards only and a forward launches warp+correlation for levels 6, 5, 4, 3, 2, 1 in that order (dispatch k of
+    the process -> level 6 - k % 6); the batch-8 figures come from a process that launches nothing else (tools/wc_standalone.py),
+    its first two launches dropped as warm-up -- and checked against the kernel the launch policy picks for that shape."""
+    by_disp = {}
+    for r in rows:
+        by_disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
+    ids = sorted(by_disp)
+    if batch == 8:
+        pick = ids[2:]
+    else:
+        assert len(ids) % 6 == 0, f"{len(ids)} warp+correlation dispatches: not a whole number of forwards"
+        pick = [d for k, d in enumerate(ids) if 6 - k % 6 == level][1:]          # the first forward is the warm-up
+    want = EXPECT[(level, batch)]
+    for d in pick:
+        name = by_disp[d][0]["Kernel_Name"]
+        assert want in name, f"dispatch {d} picked for level {level} batch {batch} is {name!r}, expected {want}"
+    return by_disp, pick
+
+
+def trace_duration_us():
+    """Average duration of the same launches in the plain --kernel-trace pass (no counters)."""
+    rows = []
+    sub = "b8_trace" if batch == 8 else "net_trace"
+    for path in glob.glob(os.path.join(out_dir, sub, "**", "*kernel_trace.csv"), recursive=True):
+        rows += [r for r in csv.DictReader(open(path)) if "warp_corr" in r["Kernel_Name"]]
+    if not rows:
+        return None, 0
+    by_disp, pick = pick_dispatches(rows)
+    d = [(int(by_disp[k][0]["End_Timestamp"]) - int(by_disp[k][0]["Start_Timestamp"])) * 1e-3 for k in pick]
+    return sum(d) / len(d), len(d)
+
+
+def counters(tag):
+    """Counter values of the level's launches in the --pmc pass `tag`."""
+    rows = []
+    sub = ("b8_" if batch == 8 else "net_") + tag
+    for path in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        rows += [r for r in csv.DictReader(open(path)) if "warp_corr" in r["Kernel_Name"]]
     by_disp, pick = pick_dispatches(rows)
     vals = {}
     for d in pick:
