@@ -15,8 +15,15 @@ bench = open(f"{R}/bench_default.json").read().strip().splitlines()[-1]
 trace = glob.glob(f"{R}/prof_fp32/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(trace)))
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-d3 = [dur(r) for r in rows if "warp_corr_v7_kernel<true>" in r["Kernel_Name"] and r.get("Grid_Size_X") == "262144"]
-d1 = [x for x in (dur(r) for r in rows if "warp_corr_v6_kernel<true, 2>" in r["Kernel_Name"]) if x > 60]
+# a forward launches warp+correlation for levels 6, 5, 4, 3, 2, 1 in that order: launch k of the process -> level 6 - k % 6; the
+# kernel each pick must be is checked (the launch policy or the forward changing fails loudly instead of mislabelling a row)
+wc = sorted((r for r in rows if "warp_corr" in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))
+assert len(wc) % 6 == 0, f"{len(wc)} warp+correlation launches: not a whole number of forwards"
+lvl = lambda L: [r for k, r in enumerate(wc) if 6 - k % 6 == L][1:]        # the first forward is the warm-up
+assert all("warp_corr_v7_kernel<true>" in r["Kernel_Name"] for r in lvl(3)), "level 3 is not the one-tile-per-CU kernel"
+assert all("warp_corr_v6_kernel<true, 2>" in r["Kernel_Name"] for r in lvl(1)), "level 1 is not the persistent kernel"
+d3 = [dur(r) for r in lvl(3)]
+d1 = [dur(r) for r in lvl(1)]
 l3 = (f"Level-3 warp+correlation launches (`warp_corr_v7_kernel<true>`, grid 256 x 1024): n={len(d3)} avg {sum(d3) / len(d3):.2f} us "
       f"min {min(d3):.2f} max {max(d3):.2f} -> {24707072 / (sum(d3) / len(d3)) / 1e3:.0f} GB/s algorithmic")
 l1 = (f"Level-1 warp+correlation launches (`warp_corr_v6_kernel<true, 2>`, 395 MB): n={len(d1)} avg {sum(d1) / len(d1):.2f} us "
