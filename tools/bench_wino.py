@@ -58,8 +58,7 @@ def stamps(a):
                 tot = t[:, 6].mean()
                 print(f"L{L} {ci}->{co} {'one workgroup' if one else 'two workgroups'} per CU: {len(t)} workgroups stamped, {nch} chunks; ticks per workgroup (mean): " +
                       "  ".join(f"{nm} {t[:, i].mean():.0f} ({100 * t[:, i].mean() / tot:.0f} %)" for i, nm in enumerate(names)), flush=True)
-                print("    per chunk: " + "  ".join(f"{nm} {t[:, i].mean() / nch:.0f}" for i, nm in list(enumerate(names))[1:5]) +
-                      f"   | of the prologue, kernel entry -> first load issued: {t[:, 7].mean():.0f} ticks", flush=True)
+                print("    per chunk: " + "  ".join(f"{nm} {t[:, i].mean() / nch:.0f}" for i, nm in list(enumerate(names))[1:5]), flush=True)
             lib.pivlfn_conv_destroy(h)
 
 
