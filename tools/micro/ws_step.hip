@@ -8,8 +8,10 @@
 #include <cstdio>
 #include <vector>
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// (prio >> 4) == 3: the MFMA waves issue v_mfma_f32_32x32x16_bf16 instead (64 per step): is the serialisation a property of the fp32 instruction?
 // prio bits: 1 = s_setprio 3 in the MFMA waves, 2 = in the second waves, 4 = stamps, 16/32 = MFMA accumulators (one: four dependent in a row, two), 256 = waves 4-7 issue
 // the MFMAs and waves 0-3 the mix (the older wave of a SIMD is then the mixed one)
 // mix bits: 1 = 6 ds_write_b128, 2 = 8 ds_read_b128 + use, 4 = 40 scalar instructions, 8 = 32 vector fmas, 16 = 2 buffer-like global loads
@@ -32,7 +34,13 @@ __global__ __launch_bounds__(512, 1) void k(const float *src, float *dst, long l
         long long work = 0, tl = t0;
         for (int s = 0; s < steps; ++s) {
             if (mfma_on) {
-                if constexpr (nacc == 0) {
+                if constexpr (nacc == 3) {      // the bf16 instruction (an XDL op, 32 cycles): 64 per step = the same 2048 cycles
+                    bf16x8 ab;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ab[e] = (__bf16)a;
+#pragma unroll
+                    for (int q = 0; q < 64; ++q) acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc[q & 7], 0, 0, 0);
+                } else if constexpr (nacc == 0) {
 #pragma unroll
                     for (int q = 0; q < 32; ++q) acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q & 7], 0, 0, 0);
                 } else if constexpr (nacc == 1) {
@@ -120,7 +128,7 @@ int main()
     const int steps = 400, nb = 256;
     struct { int mix; const char *what; } mixes[] = {{0, "nothing"}, {64, "16 ds_write_b128"}, {2, "8 ds_read_b128"}, {128, "200 scalar adds"},
                                                      {8, "32 vector fmas"}, {8 | 256, "320 vector fmas"}, {16, "2 global loads (used a step later)"}, {1 | 2 | 4 | 8 | 16, "writes+reads+scalar+fmas+loads"}};
-    for (int prio : {0, 8, 8 + 16, 8 + 256})
+    for (int prio : {0, 48, 8, 8 + 48, 8 + 16, 8 + 256})
         for (auto &m : mixes) {
             double per[2] = {0, 0}, wc[2] = {0, 0}, wp[2] = {0, 0};
             for (int mf = 0; mf < 2; ++mf) {
@@ -129,6 +137,7 @@ int main()
                     case 0: hipLaunchKernelGGL((k<0, false>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, steps, mf, m.mix, prio); break;
                     case 1: hipLaunchKernelGGL((k<1, false>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, steps, mf, m.mix, prio); break;
                     case 2: hipLaunchKernelGGL((k<2, false>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, steps, mf, m.mix, prio); break;
+                    case 3: hipLaunchKernelGGL((k<3, false>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, steps, mf, m.mix, prio); break;
                     case 16: hipLaunchKernelGGL((k<0, true>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, steps, mf, m.mix, prio); break;
                     case 17: hipLaunchKernelGGL((k<1, true>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, steps, mf, m.mix, prio); break;
                     default: hipLaunchKernelGGL((k<2, true>), dim3(nb), dim3(512), 0, 0, src, dst, ticks, steps, mf, m.mix, prio); break;
