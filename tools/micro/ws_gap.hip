@@ -1,11 +1,16 @@
 // When does the second wave of a SIMD get vector instructions issued beside a wave that streams v_mfma_f32_32x32x2_f32?
 // (tools/micro/ws_stall.hip: beside a gapless MFMA stream a vector probe keeps its pace; with one `s_nop 15` behind every MFMA it
 // does not run at all.)  Here the MFMA wave's stream has the shape of a real K step: groups of 8 MFMAs with something between them.
-// Waves 0-3: `blocks` x [4 groups of 8 MFMAs, BETWEEN after each group, END after the fourth]; waves 4-7: a probe of 16 independent
-// fmas per iteration, free-running (no barrier unless END says so).
-//   BETWEEN: 0 nothing, 1 s_nop 0, 2 two global loads + one ds_read_b128 (results used 3 groups later), 3 = 2 + one v_add_u32,
-//            4 one v_add_u32, 5 s_waitcnt vmcnt(0)+lgkmcnt(0) on nothing, 6 s_nop 3, 7 s_sleep 0... see `what` strings
-//   END:     0 nothing, 1 s_barrier (the probe waves pass one barrier per 34 probe iterations ~ one MFMA block)
+// Waves 0-3: `blocks` x [4 groups of 8 MFMAs, BETWEEN after each group, END after the fourth]; waves 4-7: per block either 128 fmas
+// (PROBE 0) or a producer-like step -- 8 ds_read_b128, 16 packed adds, 4 ds_write_b128 (PROBE 1).
+//   BETWEEN: 0 nothing, 1 s_nop 0, 6 s_nop 3, 7 four scalar adds, 5 s_waitcnt 0 on nothing, 4 one v_add_u32, 2 two global loads + one
+//            ds_read_b128 (results used 3 groups later), 3 = 2 + one v_add_u32
+//   END:     0 nothing (free-running waves), 1 one s_barrier per block for both kinds of wave
+//   BURST:   that many v_nop at the start of the second wave's step (does vector work in flight while the partner's first MFMA of the
+//            block enters the pipe change anything?  no);  DELAY: s_nop 1 / 7 / 15 in the MFMA wave behind the barrier
+// What it shows (round 5, profiles/r05_ws_gap.log): free-running, the producer-like step runs beside the MFMAs at its pace alone
+// (229 vs 230 cycles) while the dense fma stream takes 5 x longer; with a barrier per block every mix is executed AFTER the block
+// (the step is the sum), whatever BURST / DELAY.
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/ws_gap.hip -o tools/micro/ws_gap && tools/micro/ws_gap
 #include <hip/hip_runtime.h>
 #include <cstdio>
