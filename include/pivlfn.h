@@ -35,7 +35,7 @@ typedef struct {
 } pivlfn_tensor;
 
 const char *pivlfn_last_error(void);
-/* ABI version.  2 (round 4): + pivlfn_warp_corr_nhwc_timed, pivlfn_conv2d_nhwc_wino4, pivlfn_conv_create_cat, pivlfn_conv2d_nhwc_cat; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
+/* ABI version.  3 (round 6): + pivlfn_conv2d_nhwc_wino_b3, PIVLFN_PRECISION_F32_WINO_MFMA32.  2 (round 4): + pivlfn_warp_corr_nhwc_timed, pivlfn_conv2d_nhwc_wino4, pivlfn_conv_create_cat, pivlfn_conv2d_nhwc_cat; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
  * (added in round 3 without a bump).  No entry point of version 1 changed its signature or meaning. */
 int         pivlfn_abi_version(void);
 
@@ -171,6 +171,12 @@ int pivlfn_conv2d_nhwc_split(const pivlfn_conv *conv, const float *x, int x_stri
  * fp32 y, output grid = input grid. */
 int pivlfn_conv2d_nhwc_wino(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                             int B, int H, int W, int leaky, void *stream);
+/* The same layer (3 x 3, stride 1, pad 1, no residual; cout rounded up to 32 a multiple of 64) by Winograd F(2x2, 3x3) with every
+ * fp32 operand split exactly into three bf16 pieces (8 + 8 + 8 significand bits, fp32's exponent range) and the products formed
+ * on v_mfma_f32_32x32x16_bf16 (csrc/conv_wino_b3.hip): terms = 6 (dropped piece products <= 2^-23 of a product, typically 2^-26), 8
+ * (<= 2^-32) or 9 (the exact product of the two fp32 operands).  fp32 x, fp32 y. */
+int pivlfn_conv2d_nhwc_wino_b3(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                               int B, int H, int W, int leaky, int terms, void *stream);
 /* The same layer on the Winograd F(4x4, 3x3) kernel (6 x 6 transforms; relative error ~1e-5 against ~1.4e-6 of F(2x2)).  Measured
  * and kept as an entry point only: pivlfn_forward does not use it (0.98x of F(2x2) on 128->128 at 1024 x 1024, slower below). */
 int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,

@@ -71,6 +71,8 @@ int conv_head_forward(const pivlfn_conv *c, const float *x, const float *res4, f
 int conv_create_cat(const float *weight, const float *bias, int cout, int nsrc, const int *channels, int kh, int kw, pivlfn_conv **out);
 int conv_forward_cat(const pivlfn_conv *c, int nsrc, const float *const *x, const int *x_stride, float *y, int y_stride,
                      int B, int H, int W, int leaky, hipStream_t st);
+int conv_forward_wb(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, int B, int H, int W, int leaky,
+                    int terms, hipStream_t st);
 int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, int B, int H, int W, int leaky,
                    hipStream_t st, int tile);
 
@@ -81,7 +83,7 @@ using namespace pivlfn;
 extern "C" {
 
 const char *pivlfn_last_error(void) { return g_err; }
-int pivlfn_abi_version(void) { return 2; }
+int pivlfn_abi_version(void) { return 3; }
 
 #ifdef PIVLFN_TOOLS
 int pivlfn_tune(int knob, int value)
@@ -182,6 +184,12 @@ int pivlfn_conv2d_nhwc_wino(const pivlfn_conv *conv, const float *x, int x_strid
                             int B, int H, int W, int leaky, void *stream)
 {
     return conv_forward_w(conv, x, x_stride, y, y_stride, B, H, W, leaky, (hipStream_t)stream, 2);
+}
+
+int pivlfn_conv2d_nhwc_wino_b3(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
+                               int B, int H, int W, int leaky, int terms, void *stream)
+{
+    return conv_forward_wb(conv, x, x_stride, y, y_stride, B, H, W, leaky, terms, (hipStream_t)stream);
 }
 
 int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,

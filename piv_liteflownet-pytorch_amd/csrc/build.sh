@@ -5,7 +5,7 @@
 #                     stamps); only tools/*.py load it
 set -e
 cd "$(dirname "$0")"
-SRCS="conv_mfma conv_wino conv_wino4 conv_f16 conv_split conv_head warp_corr corr_bwd ops net api"
+SRCS="conv_mfma conv_wino conv_wino_b3 conv_wino4 conv_f16 conv_split conv_head warp_corr corr_bwd ops net api"
 build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags, $4 = extra sources
   local OBJ="$1" OUT="$2" SRCS="$SRCS $4"
   mkdir -p "$OBJ"

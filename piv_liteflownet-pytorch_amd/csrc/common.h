@@ -187,8 +187,12 @@ struct ConvParamsW {
     int nchunk, lrelu;
     unsigned long long *stamps;   // tools build (-DPIVLFN_STAMPS) only: per-workgroup phase times of wave 0 (s_memtime ticks), 8 per workgroup; nullptr in production
     int dbg;            // tools build only: ablation mask of conv_wino_ws.hip (timing runs, wrong results)
+    const void *wpk_b;  // conv_wino_b3.hip: the same U split into three bf16 pieces, [nchunk][cout_pad/64][4][4][2][3][64][8] (pack_conv_wb); nchunk = K steps of 16 channels
+    int terms;          // conv_wino_b3.hip: piece products per product, 6 (default), 8 or 9
 };
 int launch_conv_w(const ConvParamsW &p, hipStream_t st);
+int launch_conv_wb(const ConvParamsW &p, hipStream_t st);      // the same layers with exactly split operands on the bf16 matrix cores (conv_wino_b3.hip)
+bool conv_wino_b3_supports(int cout_pad);
 int launch_conv_w_ws(const ConvParamsW &p, hipStream_t st);   // the same layers on persistent workgroups with producer / consumer waves (conv_wino_ws.hip); bit-identical
 long conv_wino_ws_items(const ConvParamsW &p);                // work items such a launch would have (0: not covered)
 int launch_conv_w4(const ConvParamsW &p, hipStream_t st);      // F(4x4, 3x3): wpk = [nchunk][cout_pad/32][6][6][64][4] (pack_conv_w4)

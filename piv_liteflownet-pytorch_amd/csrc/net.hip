@@ -28,6 +28,8 @@ void pack_conv_w(const float *w, int cout, int cin, const int *creal, const int 
                  std::vector<float> &pk, int *nchunk_out);
 void pack_conv_w4(const float *w, int cout, int cin, const int *creal, const int *cload, const int *coff, int nseg,
                  std::vector<float> &pk, int *nchunk_out);      // conv_wino.hip
+void pack_conv_wb(const float *w, int cout, int cin, const int *creal, const int *cload, const int *coff, int nseg,
+                  std::vector<unsigned short> &pk, int *nstep_out);      // conv_wino_b3.hip
 
 struct ConvW {
     float *wpk = nullptr, *bias = nullptr;
@@ -43,6 +45,8 @@ struct ConvW {
     float *wpk_w = nullptr;        // 3 x 3 layers: Winograd-domain weights G g G^T in fragment order (conv_wino.hip)
     float *wpk_w4 = nullptr;       // the same for F(4x4, 3x3): 36 planes (conv_wino4.hip)
     int nchunk_w = 0, nchunk_w4 = 0;
+    void *wpk_wb = nullptr;        // 3 x 3 layers with whole 64-channel groups: the Winograd-domain weights as three bf16 pieces each (conv_wino_b3.hip)
+    int nstep_wb = 0;
 };
 
 struct LevelW {
@@ -228,6 +232,15 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
             pack_conv_w4(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w4);
             rc = upload(net, pw, &out->wpk_w4);
             if (rc) return rc;
+        }
+        if (conv_wino_b3_supports(cp)) {
+            std::vector<unsigned short> pb;
+            pack_conv_wb(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pb, &out->nstep_wb);
+            void *d = nullptr;
+            PIV_CHECK_HIP(hipMalloc(&d, pb.size() * sizeof(unsigned short)));
+            net->allocs.push_back(d);
+            PIV_CHECK_HIP(hipMemcpy(d, pb.data(), pb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            out->wpk_wb = d;
         }
     }
     if (conv_split_supports(kh, kw, 1, cp, 6)) {   // the split-operand packing of the same layer (fp32 on the fp16 matrix cores)
@@ -839,6 +852,25 @@ int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y,
         return launch_conv_w4(q, st);
     }
     return launch_conv_w(q, st);
+}
+
+// Standalone 3 x 3 / stride 1 / pad 1 layer on the split-operand Winograd kernel (conv_wino_b3.hip): fp32 in, fp32 out; terms = 6, 8 or 9.
+int conv_forward_wb(const pivlfn_conv *c, const float *x, int x_stride, float *y, int y_stride, int B, int H, int W, int leaky,
+                    int terms, hipStream_t st)
+{
+    PIV_REQUIRE(c && x && y, "conv2d_wino_b3: null argument");
+    PIV_REQUIRE(c->cw.wpk_wb, "conv2d_wino_b3: the layer is not 3 x 3 with whole 64-channel output groups (k=%dx%d, cout_pad=%d)", c->cw.KH, c->cw.KW, c->cw.cout_pad);
+    PIV_REQUIRE(x_stride % 4 == 0 && x_stride >= rup(c->cin, 4), "conv2d_wino_b3: x_stride=%d must be a multiple of 4 and >= %d", x_stride, rup(c->cin, 4));
+    PIV_REQUIRE(y_stride % 4 == 0 && y_stride >= c->cw.cout, "conv2d_wino_b3: y_stride=%d must be a multiple of 4 and >= cout=%d", y_stride, c->cw.cout);
+    ConvParamsW q;
+    memset(&q, 0, sizeof(q));
+    q.seg[0] = ConvSeg{x, rup(c->cin, 4), x_stride};
+    q.nseg = 1;
+    q.wpk_b = c->cw.wpk_wb; q.bias = c->cw.bias; q.out = y; q.out_stride = y_stride;
+    q.cout_store = std::min(rup(c->cw.cout, 4), y_stride);
+    q.cout_pad = c->cw.cout_pad;
+    q.B = B; q.H = H; q.W = W; q.nchunk = c->cw.nstep_wb; q.lrelu = leaky; q.terms = terms;
+    return launch_conv_wb(q, st);
 }
 
 int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *flow, float *levels, int B, int H, int W,

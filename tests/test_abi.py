@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert set(_declared()) == set(_lib.SIGNATURES), "ctypes prototypes out of sync with the header"
     assert not hasattr(lib, "pivlfn_tune"), "the production library must not export the tools-only knob setter"
     loaded = _lib.load()
-    assert loaded.pivlfn_abi_version() == 2
+    assert loaded.pivlfn_abi_version() == 3
     assert loaded.pivlfn_last_error() is not None
 
 

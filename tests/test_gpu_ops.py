@@ -19,7 +19,7 @@ def rel(a, b):
 
 def test_native_library_is_the_one_loaded(dev):
     lib = _lib.load()
-    assert lib.pivlfn_abi_version() == 2
+    assert lib.pivlfn_abi_version() == 3
     assert "libpivlfn.so" in open("/proc/self/maps").read()
 
 

@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--layers", default="")
     ap.add_argument("--ab", default="", help="path of a second build of libpivlfn.so: its Winograd kernel is timed beside the current one (interleaved rounds)")
+    ap.add_argument("--b3", default="", help="also time the split-operand Winograd kernel (conv_wino_b3.hip) with these piece-product counts, e.g. 6 or 6,8,9 (instead of F(4x4))")
     ap.add_argument("--w4", action="store_true", help="--masks are ablation masks of the F(4x4) kernel (1 no MFMAs, 2 no transform, 4 no weight loads, 8 no patch loads, 16 no epilogue)")
     ap.add_argument("--masks", default="", help="tools build only: per-variant masks of the Winograd kernel: (m >> 8) & 255 = forced tile shape (11, 21, 22, 14; 30 = never / 31 = always the wave-specialised kernel), 65536 = one workgroup per CU, m >> 24 = ablation mask of the wave-specialised kernel")
     ap.add_argument("--stamps", action="store_true", help="tools build only: phase times of wave 0 of every workgroup (s_memtime ticks) for the two-block shape, at two and at one workgroup per CU")
@@ -159,6 +160,15 @@ def main():
             def wino4():
                 _lib.check(lib.pivlfn_conv2d_nhwc_wino4(h, x.data_ptr(), xs, y["wino4"].data_ptr(), co, a.batch, n, n, 1, st), "wino4")
             fns = {"direct": direct, "wino": wino, "wino4": wino4}
+            if a.b3:
+                fns = {"direct": direct, "wino": wino}
+                if co % 64 == 0:
+                    for t in [int(v) for v in a.b3.split(",")]:
+                        y[f"b3_{t}"] = torch.empty(a.batch, n, n, co, device=dev)
+
+                        def b3(t=t):
+                            _lib.check(lib.pivlfn_conv2d_nhwc_wino_b3(h, x.data_ptr(), xs, y[f"b3_{t}"].data_ptr(), co, a.batch, n, n, 1, t, st), "wino_b3")
+                        fns[f"b3_{t}"] = b3
             if lib_b is not None:
                 hb = ctypes.c_void_p()
                 _lib.check(lib_b.pivlfn_conv_create(w.data_ptr(), b.data_ptr(), co, ci, 3, 3, ctypes.byref(hb)), "create b")
@@ -232,6 +242,12 @@ def main():
             print(f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}: direct min {td:8.1f} med {md:8.1f} us ({flop / td / 1e6:6.1f} TF)   "
                   f"wino min {tw:8.1f} med {mw:8.1f} us ({flop / tw / 1e6:6.1f} TF-equiv, {flop / 2.25 / tw / 1e6:6.1f} TF executed)   "
                   f"x{td / tw:4.2f}   rel diff {d:.1e}", flush=True)
+            for k in [k for k in times if k.startswith("b3_")]:
+                db = (y[k] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
+                tb, mb_ = min(times[k]), sorted(times[k])[len(times[k]) // 2]
+                t_ = int(k[3:])
+                print(f"        split bf16 x {t_}: min {tb:8.1f} med {mb_:8.1f} us ({flop / tb / 1e6:6.1f} TF-equiv, {flop / 2.25 * t_ / tb / 1e9:6.3f} PF bf16 executed)   "
+                      f"x{td / tb:4.2f} vs direct, x{tw / tb:4.2f} vs fp32 Winograd   rel diff {db:.1e}", flush=True)
             if "wino4" in times:
                 d4 = (y["wino4"] - y["direct"]).abs().max().item() / y["direct"].abs().max().item()
                 t4, m4 = min(times["wino4"]), sorted(times["wino4"])[len(times["wino4"]) // 2]
