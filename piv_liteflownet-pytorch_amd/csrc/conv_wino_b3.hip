@@ -50,28 +50,18 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-// LDS image of one K step's patch (18 x 18 pixels x 16 channels fp32), filled by LDS-DMA (buffer_load_dwordx4 ... lds: no staging
-// registers, no ds_write): four planes, one per 16-byte channel quad; inside a plane rows and columns are de-interleaved (even then odd)
-// as in conv_wino.hip, pixel pitch 1 quad, row pitch 24 quads = 8 mod 16: the 16 lanes of every ds_read_b128 group (tile rows {0,3} x
-// columns 0-3 and rows {1,2} x columns 4-7, or the complement) land on 16 distinct 16-byte slots.  A plane is 448 quads = 7 wave-loads
-// of 64 consecutive quads: wave w fills plane w -- the channel quad is wave-uniform (a scalar offset; past the source's channels the
-// whole instruction goes through a null descriptor and writes zeros).
-constexpr int BROWQ = 24;       // quads per patch row inside a plane: 18 pixels + 6 of padding
+// LDS image of one K step's patch (18 x 18 pixels x 16 channels fp32): pixel records of 4 channel quads + 1 quad of padding (odd
+// pitch), rows and columns de-interleaved (even then odd) as in conv_wino.hip, row pitch 104 quads = 8 mod 16: the 16 lanes of every
+// ds_read_b128 group (tile rows {0,3} x columns 0-3 and rows {1,2} x columns 4-7, or the complement) land on 16 distinct 16-byte slots.
+// Staged through registers (buffer_load_dwordx4 -> ds_write_b128, four lanes per 64-byte pixel record).  LDS-DMA was built and measured
+// (git history): a DMA lands ~3000 cycles after its issue here, and the in-order vmcnt makes the first wait for a LATER weight-fragment
+// load wait for it as well -- one phase (~1200 cycles) of slack.
+constexpr int BPIXQ = 5;        // 16-byte quads per staged pixel: 16 channels + 4 floats of padding
+constexpr int BROWQ = 104;      // quads per patch row: 18 x 5 = 90, padded to 8 mod 16
 constexpr int BPH = 18;         // patch rows = columns: 8 tiles x 2 + 2
-constexpr int BPLANE = 448;     // quads per channel-quad plane: 18 x 24 = 432, padded to 7 x 64
-constexpr int BPBUF = 4 * BPLANE;           // quads per patch buffer
-constexpr int BPS = BPLANE / 64;            // DMA loads per wave and step
+constexpr int BPBUF = BPH * BROWQ + 8;      // quads per patch buffer (+ a spare record for slots past the patch)
+constexpr int BPS = 6;          // staging slots per thread: three patch rows each
 constexpr int BWAVE = 4 * 2 * 3 * 64;       // u32x4 per (step, channel group, wave): [plane col 4][channel block 2][piece 3][lane 64]
-using i32x4 = __attribute__((ext_vector_type(4))) int;
-
-// Raw buffer descriptor (stride 0, 32-bit float format word as __builtin_amdgcn_make_buffer_rsrc's 0x00020000) for the LDS-DMA
-// statements below, which take it as four scalar registers
-__device__ __forceinline__ i32x4 make_rsrc(const void *base, unsigned bytes)
-{
-    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-    return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
 {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));      // v_cvt_pk_bf16_f32: round to nearest even
@@ -121,6 +111,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, g = lane >> 5;
 
+    // staging: slot s (0..5) of a thread covers patch rows 3 s .. 3 s + 2: thread -> (row r = 0..2 inside the slot, column px, quad); 216 of the
+    // 256 threads carry a record.  A thread's global offset is then ONE value + s x (3 image rows) and its LDS offset one of TWO values
+    // (even / odd slots: the de-interleaved row order) + a constant: 4 registers where a slot table takes 12 (which the register allocator
+    // spilled, and a spill reload waits vmcnt(0) -- for the patch loads in flight and for the epilogue's stores).
+    const int q4 = (tid & 3) * 4;
+    const int spix = tid >> 2, sr = spix >= 54 ? 3 : (spix >= 36 ? 2 : (spix >= 18 ? 1 : 0)), spx = spix - 18 * sr;
+    const int scol = sr < 3 ? ((spx >> 1) + (spx & 1) * 9) * BPIXQ + (tid & 3) : 90 + (tid & 3);      // idle threads: the padding at the end of a row
+    const int plds_even = (sr < 3 ? ((sr >> 1) + (sr & 1) * 9) * BROWQ : 0) + scol;
+    const int plds_odd = (sr < 3 ? (((sr + 1) >> 1) + (1 - (sr & 1)) * 9) * BROWQ : 0) + scol;
     // plane row i = wave: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     int abase[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
-        abase[mb] = 2 * g * BPLANE + (mb * 4 + (n >> 3) + (ra >> 1) + (ra & 1) * (BPH / 2)) * BROWQ + (n & 7);      // patch pixel (2 tyl + ra, 2 txl), quad planes 2 g, 2 g + 1
+        abase[mb] = (mb * 4 + (n >> 3) + (ra >> 1) + (ra & 1) * (BPH / 2)) * BROWQ + (n & 7) * BPIXQ + 2 * g;      // patch pixel (2 tyl + ra, 2 txl), quads 2 g, 2 g + 1
     const int abdiff = (((rb >> 1) + (rb & 1) * (BPH / 2)) - ((ra >> 1) + (ra & 1) * (BPH / 2))) * BROWQ;             // row rb from row ra (wave-uniform)
 
     // (starting a tile's accumulators from the constant 0 in its first MFMAs, as conv_wino.hip does, costs a second copy of the step
@@ -151,19 +150,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     // ---- the load stream: (tile, step) whose patch is fetched next, two steps ahead of the matrix work and across tile boundaries
     const size_t img_px = (size_t)p.H * p.W;
     int ltile = ctile, lseg = 0, lc0 = 0, ly0 = 0, lx0 = 0, lrow0 = 0;
-    i32x4 rsv[3];
-    const i32x4 rnull = make_rsrc(p.bias, 0);      // no records: every load reads zeros
-    unsigned pvo[BPS];              // byte offset of the pixel record of this lane's position in wave-load s of its plane, inside the load tile's current source; WOOB = none (padding, outside the image)
+    __amdgpu_buffer_rsrc_t rsv[3];
+    // byte offset of the thread's record in slot 1..5 (+ s x lrstep) and in slot 0, inside the load tile's current source (the descriptor
+    // starts one row above the tile: at the patch's first row); WOOB = none (left / right / top padding, idle thread); rows below the image
+    // fall behind the descriptor's end
+    unsigned pvo_base = WOOB, pvo_first = WOOB;
+    int lrstep = 0;
 #define B3_PVO(SEG)                                                                               \
     do {                                                                                          \
         const int sst4_ = p.seg[SEG].stride * 4;                                                  \
-        _Pragma("unroll") for (int s = 0; s < BPS; ++s) {                                         \
-            const int l_ = 64 * s + lane, r_ = l_ / BROWQ, c_ = l_ - r_ * BROWQ;                  \
-            const int py_ = r_ < 9 ? 2 * r_ : 2 * (r_ - 9) + 1, px_ = c_ < 9 ? 2 * c_ : 2 * (c_ - 9) + 1; \
-            const int iy_ = ly0 - 1 + py_, ix_ = lx0 - 1 + px_;                                   \
-            const bool in_ = r_ < BPH && c_ < BPH && iy_ >= 0 && iy_ < p.H && ix_ >= 0 && ix_ < p.W; \
-            pvo[s] = in_ ? (unsigned)((iy_ - lrow0) * p.W + ix_) * (unsigned)sst4_ : WOOB;        \
-        }                                                                                         \
+        int tid_ = tid;                                                                           \
+        asm volatile("" : "+v"(tid_));     /* laundered: nothing derived from it is kept in registers as a loop invariant */ \
+        const int spix_ = tid_ >> 2, sr_ = spix_ >= 54 ? 3 : (spix_ >= 36 ? 2 : (spix_ >= 18 ? 1 : 0)), ix_ = lx0 - 1 + spix_ - 18 * sr_; \
+        lrstep = 3 * p.W * sst4_;                                                                 \
+        pvo_base = sr_ < 3 && ix_ >= 0 && ix_ < p.W ? (unsigned)(sr_ * p.W + ix_) * (unsigned)sst4_ + (unsigned)(tid_ & 3) * 16u : WOOB; \
+        pvo_first = ly0 == 0 && sr_ == 0 ? WOOB : pvo_base;      /* patch row 0 of a tile in the first image row: the zero padding */ \
     } while (0)
 // descriptors of the load tile: they start at the first image row of its patch (64-bit scalar arithmetic), the 32-bit lane offsets span
 // the patch rows only
@@ -174,34 +175,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         t_ /= tiles_x;                                                                            \
         ly0 = (t_ % tiles_y) * 16;                                                                \
         const int lb_ = t_ / tiles_y;                                                             \
-        lrow0 = max(ly0 - 1, 0);                                                                  \
+        lrow0 = ly0 - 1;                                                                          \
         _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                           \
             const int ss = s < p.nseg ? s : 0;                                                    \
             const size_t left = ((size_t)(p.H - lrow0) * p.W - 1) * p.seg[ss].stride + p.seg[ss].cload; \
-            rsv[s] = make_rsrc(p.seg[ss].ptr + ((size_t)lb_ * img_px + (size_t)lrow0 * p.W) * p.seg[ss].stride, (unsigned)min(left * 4, (size_t)0x7fffffff)); \
+            rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[ss].ptr) + ((long)lb_ * (long)img_px + (long)lrow0 * p.W) * p.seg[ss].stride, 0, \
+                                                       (unsigned)min(left * 4, (size_t)0x7fffffff), 0x00020000); \
         }                                                                                         \
         lseg = 0; lc0 = 0;                                                                        \
         B3_PVO(0);                                                                                \
     } while (0)
-// patch of the load stream's step -> the image at quad offset BOFF (this wave's channel quad of every pixel), then advance the stream
-// inside its tile.  The stream changes tiles in ONE place, B3_LNEXT, two steps before the matrix work does.
-// The seven loads are ONE assembly statement the compiler does not see into: a builtin LDS-DMA makes hipcc wait vmcnt(0) in front of
-// every later ds_read it cannot prove disjoint (all of them: the image being read and the image being filled are the same array) and
-// in front of the next use of any ordinary load -- the whole HBM latency in the middle of a step.  Its completion is counted by hand:
-// B3_WAITDMA in front of the step's closing barrier.  M0 = LDS byte address of the wave-load (inside the first 64 KB).
-#define B3_DMA(BOFF)                                                                              \
+// patch of the load stream's step -> PR, then advance the stream inside its tile (the loads and this rare branch sit at the top of a
+// step: everything behind them is one basic block).  The stream changes tiles in ONE place, B3_LNEXT, two steps before the matrix work does.
+#define B3_LOADP(PR)                                                                              \
     do {                                                                                          \
         const int scl_ = p.seg[lseg].cload;                                                       \
-        const i32x4 rs_ = lc0 + 4 * wave < scl_ ? (lseg == 0 ? rsv[0] : (lseg == 1 ? rsv[1] : rsv[2])) : rnull; \
-        asm volatile("s_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %7, %8 offen lds\n\t"      \
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, %8 offen lds\n\t" \
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, %8 offen lds\n\t" \
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %8 offen lds\n\t" \
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %8 offen lds\n\t" \
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, %8 offen lds\n\t" \
-                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, %8 offen lds"       \
-                     :: "v"(pvo[0]), "v"(pvo[1]), "v"(pvo[2]), "v"(pvo[3]), "v"(pvo[4]), "v"(pvo[5]), "v"(pvo[6]), "s"(rs_), \
-                        "s"(lc0 * 4 + wave * 16), "s"(((BOFF) + wave * BPLANE) * 16) : "memory", "scc"); \
+        const __amdgpu_buffer_rsrc_t rs_ = lseg == 0 ? rsv[0] : (lseg == 1 ? rsv[1] : rsv[2]);    \
+        const bool qok_ = lc0 + q4 < scl_;                                                        \
+        _Pragma("unroll") for (int s = 0; s < BPS; ++s)                                           \
+            PR[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? (s ? pvo_base + (unsigned)(s * lrstep) : pvo_first) : WOOB), lc0 * 4, 0)); \
         lc0 += 16;                                                                                \
         if (lc0 >= scl_ && lseg + 1 < p.nseg) {                                                   \
             ++lseg;                                                                               \
@@ -209,8 +201,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
             B3_PVO(lseg);                                                                         \
         }                                                                                         \
     } while (0)
-// every LDS-DMA of this wave has landed (the N youngest vector-memory operations may still be in flight)
-#define B3_WAITDMA(N) __builtin_amdgcn_s_waitcnt(0x0F70 | (N))
+#define B3_COMMIT(PR, BOFF)                                                                       \
+    do {                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < BPS; ++s)                                           \
+            smem4[(BOFF) + ((s & 1) ? plds_odd + ((3 * s - 1) / 2) * BROWQ : plds_even + (3 * s / 2) * BROWQ)] = PR[s]; \
+    } while (0)
 // the load stream moves on to this workgroup's next tile (past the last one: every slot out of range -- zeros, no memory access)
 #define B3_LNEXT()                                                                                \
     do {                                                                                          \
@@ -219,15 +214,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
             B3_LTILE();                                                                           \
         } else {                                                                                  \
             lseg = 0; lc0 = 0;                                                                    \
-            _Pragma("unroll") for (int s = 0; s < BPS; ++s) pvo[s] = WOOB;                        \
+            pvo_base = pvo_first = WOOB;                                                          \
         }                                                                                         \
     } while (0)
 // patch column C (0..3) of both tile blocks, rows ra / rb combined, from the image at quad offset BOFF
 #define B3_TCOL(C, BOFF)                                                                          \
     do {                                                                                          \
         _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int q = 0; q < 2; ++q) { \
-            const f32x4 a_ = smem4[(BOFF) + abase[mb] + (((C) >> 1) + ((C)&1) * 9) + q * BPLANE];  \
-            const f32x4 b_ = smem4[(BOFF) + abase[mb] + abdiff + (((C) >> 1) + ((C)&1) * 9) + q * BPLANE]; \
+            const f32x4 a_ = smem4[(BOFF) + abase[mb] + (((C) >> 1) + ((C)&1) * 9) * BPIXQ + q];  \
+            const f32x4 b_ = smem4[(BOFF) + abase[mb] + abdiff + (((C) >> 1) + ((C)&1) * 9) * BPIXQ + q]; \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) t[mb][C][q][e] = __builtin_fmaf(sb, b_[e], a_[e]); \
         }                                                                                         \
     } while (0)
@@ -281,8 +276,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_STEP(WNEXT)                                                                         \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
+        B3_LOADP(pr);                                                                             \
         B3_ULOAD(woff, 3, 1);                                                                     \
-        B3_DMA(bo2);                                                                              \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                        \
         B3_TCOL(0, bo1);                                                                          \
@@ -306,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         B3_VPLANE(0, 0);                                                                          \
         B3_MFMAS(2, 1);                                                                        \
         BSTAMP(11);                                                                               \
-        B3_WAITDMA(6);              /* the six fragment loads of the next step's first plane stay in flight */ \
+        B3_COMMIT(pr, bo2);                                                                       \
         __syncthreads();                                                                          \
         BSTAMP(12);                                                                               \
         const int tt_ = bo1; bo1 = bo2; bo2 = tt_;                                                \
@@ -316,8 +311,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_STEP_LAST(WNEXT)                                                                       \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
+        B3_LOADP(pr);                                                                             \
         B3_ULOAD(woff, 3, 1);                                                                     \
-        B3_DMA(bo2);                                                                              \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                    \
         B3_WAITVM();                                                                              \
@@ -332,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         woff = (WNEXT);                                                                           \
         B3_ULOAD(woff, 0, 0);                                                                     \
         B3_MFMAS(2, 1);                                                                    \
-        B3_WAITDMA(6);                                                                            \
+        B3_COMMIT(pr, bo2);                                                                       \
         __syncthreads();                                                                          \
         const int tt_ = bo1; bo1 = bo2; bo2 = tt_;                                                \
     } while (0)
@@ -341,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     // tools build: ticks (s_memtime) of wave 0 per category, summed over the workgroup's tiles: 0 tile start, 1 full steps, 2 last step,
     // 3 epilogue, 4 load-stream tile switch, 5 whole, 6 tiles, 7 steps, 8-11 the four phases of the full steps, 12 their closing barrier
     const bool stamp_ = p.stamps != nullptr && wave == 0;
-    unsigned long long tk_ = 0, t_begin_ = 0, sd_[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk_ = 0, t_begin_ = 0, sd_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (stamp_) t_begin_ = tk_ = __builtin_amdgcn_s_memtime();
 #define BSTAMP(I)                                                                                 \
     do {                                                                                          \
@@ -354,15 +349,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #else
 #define BSTAMP(I) do { } while (0)
 #endif
+    f32x4 pr[BPS];
     f32x4 t[2][4][2];               // [tile block][patch column][quad]: row-combined columns of the current step
     u32x4 V[2][2][3], U[2][2][3];   // [slot][tile block | channel block][piece]
     int bo1 = BBUF_A, bo2 = BBUF_B; // the image read during a step (the NEXT step's patch) and the buffer the step after next is committed to
     B3_LTILE();
     // prologue: the first two patches of the stream and the first weight fragments in flight together
-    B3_ULOAD(woff, 0, 0);
-    B3_DMA(bo2);
-    B3_DMA(bo1);
-    B3_WAITDMA(0);
+    {
+        f32x4 pr2[BPS];
+        B3_ULOAD(woff, 0, 0);
+        B3_LOADP(pr);
+        B3_LOADP(pr2);
+        B3_COMMIT(pr, bo2);
+        B3_COMMIT(pr2, bo1);
+    }
     __syncthreads();
 
     // p.nchunk >= 2 (launcher).  The load stream is two steps ahead: entering a tile it stands at the tile's third step, and it moves on
@@ -388,10 +388,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         }
         B3_STEP_LAST(wfirst);
         BSTAMP(2);
+        __builtin_amdgcn_sched_barrier(0);      // nothing of the epilogue is hoisted into the step (the first planes' accumulators are final early: their reads would be)
 
         // ---- output transform.  acc[jp][mb][nw][4 rg + e] = M[(wave, jp)][cout 64 ng + 32 nw + 8 rg + 4 g + e][tile n of block mb]
         // column half (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; row half across waves: Y[0] = R_0 + R_1 + R_2, Y[1] = R_1 - R_2 - R_3.
-        f32x4 *xch = smem4 + BXCH;       // [nw][wave][q][rg][lane], one tile block at a time
+        // Exchange layout per (nw, wave i, q): 256 quads, position of (tile n, channel quad c4 = 2 rg + g of the 32-channel block) =
+        // (n >> 3) * 64 + (n & 7) * 8 + (c4 ^ (n & 7)): the finishing wave reads 64 CONSECUTIVE quads per instruction (tile row k: 8 tiles x
+        // 8 channel quads), so that eight lanes hold one pixel's 32 channels and every store instruction writes eight whole 128-byte
+        // lines (a lane per tile and 16 bytes of it -- 64 lines per instruction -- took 4100 cycles per half); the XOR keeps the
+        // writers' eight-lane groups on distinct banks.
+        f32x4 *xch = smem4 + BXCH;
         int t_ = ctile;
         const int ng = t_ % NG;
         t_ /= NG;
@@ -399,20 +405,27 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         t_ /= tiles_x;
         const int y0 = (t_ % tiles_y) * 16, b = t_ / tiles_y;
         const int pp = wave >> 1, qq = wave & 1;      // this wave finishes output pixel (pp, qq) of every tile
+        // (the lane id is laundered per tile: left visible, the epilogue's per-lane addresses are loop invariants that the compiler keeps in
+        //  registers through the K steps -- and spills; a spill reload waits vmcnt(0))
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int en = ln & 31, eg = ln >> 5;
+        const int wpos = (en >> 3) * 64 + (en & 7) * 8;
+        const int rts = ln >> 3, rc4 = (ln & 7) ^ rts;     // finishing lane: tile column, channel quad
         // every load of the epilogue in front of its first store (a load behind a store waits for the store: vmcnt counts both in order)
-        f32x4 bias4[2][4];
+        f32x4 bias4[2];
 #pragma unroll
-        for (int nw = 0; nw < 2; ++nw)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) bias4[nw][rg] = *reinterpret_cast<const f32x4 *>(p.bias + (ng * 2 + nw) * 32 + 4 * g + 8 * rg);
+        for (int nw = 0; nw < 2; ++nw) bias4[nw] = *reinterpret_cast<const f32x4 *>(p.bias + (ng * 2 + nw) * 32 + 4 * rc4);
         // stores through a descriptor that starts at the tile's first image row; pixels outside the image and channels past cout_store get
         // an out-of-range offset instead of a branch
         const size_t orow = ((size_t)b * p.H + y0) * p.W;
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + orow * p.out_stride, 0,
             (unsigned)min(((size_t)(p.H - y0) * p.W) * p.out_stride * 4, (size_t)0x7fffffff), 0x00020000);
+        const int ox = x0 + 2 * rts + qq;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             if (mb) __syncthreads();            // the first half has been read
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nw = 0; nw < 2; ++nw)
 #pragma unroll
@@ -421,31 +434,34 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #pragma unroll
                     for (int jp = 0; jp < 4; ++jp)
                         m[jp] = f32x4{acc[jp][mb][nw][4 * rg + 0], acc[jp][mb][nw][4 * rg + 1], acc[jp][mb][nw][4 * rg + 2], acc[jp][mb][nw][4 * rg + 3]};
-                    xch[(((nw * 4 + wave) * 2 + 0) * 4 + rg) * 64 + lane] = (m[0] + m[1]) + m[2];
-                    xch[(((nw * 4 + wave) * 2 + 1) * 4 + rg) * 64 + lane] = (m[1] - m[2]) - m[3];
+                    const int wq = wpos + ((2 * rg + eg) ^ (en & 7));
+                    xch[((nw * 4 + wave) * 2 + 0) * 256 + wq] = (m[0] + m[1]) + m[2];
+                    xch[((nw * 4 + wave) * 2 + 1) * 256 + wq] = (m[1] - m[2]) - m[3];
                 }
             __syncthreads();
-            const int oyl = 2 * (mb * 4 + (n >> 3)) + pp, ox = x0 + 2 * (n & 7) + qq;
-            const bool ok = y0 + oyl < p.H && ox < p.W;
+            BSTAMP(13 + 0 * mb);
 #pragma unroll
             for (int nw = 0; nw < 2; ++nw) {
-                const int cb = (ng * 2 + nw) * 32 + 4 * g;
-                const unsigned obase = (unsigned)((oyl * p.W + ox) * p.out_stride + cb) * 4u;
+                const int ch = (ng * 2 + nw) * 32 + 4 * rc4;
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const f32x4 *x = xch + ((nw * 4 * 2 + qq) * 4 + rg) * 64 + lane;     // wave i at x[i * 2 * 4 * 64]
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 *x = xch + (nw * 4 * 2 + qq) * 256 + k * 64 + ln;     // wave i at x[i * 2 * 256]
                     f32x4 y;
                     if (pp == 0) y = (x[0] + x[1 * 512]) + x[2 * 512];
                     else y = (x[1 * 512] - x[2 * 512]) - x[3 * 512];
-                    y += bias4[nw][rg];
+                    y += bias4[nw];
                     if (p.lrelu) {
                         y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok && cb + 8 * rg < p.cout_store ? obase + 32u * rg : WOOB), 0, 0);
+                    const int oyl = 2 * (mb * 4 + k) + pp;
+                    const bool ok = y0 + oyl < p.H && ox < p.W && ch < p.cout_store;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok ? (unsigned)((oyl * p.W + ox) * p.out_stride + ch) * 4u : WOOB), 0, 0);
                 }
             }
+            BSTAMP(14);
         }
         B3_ZERO_ACC();
+        BSTAMP(15);
         BSTAMP(3);
 #ifdef PIVLFN_STAMPS
         if (stamp_) sd_[6] += 1;
@@ -456,15 +472,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #ifdef PIVLFN_STAMPS
     if (stamp_ && lane == 0) {
         sd_[5] = __builtin_amdgcn_s_memtime() - t_begin_;
-        for (int i = 0; i < 13; ++i) p.stamps[(size_t)blockIdx.x * 16 + i] = sd_[i];
+        for (int i = 0; i < 16; ++i) p.stamps[(size_t)blockIdx.x * 16 + i] = sd_[i];
     }
 #endif
 #undef BSTAMP
 #undef B3_PVO
 #undef B3_LTILE
-#undef B3_DMA
+#undef B3_LOADP
+#undef B3_COMMIT
 #undef B3_WAITVM
-#undef B3_WAITDMA
 #undef B3_LNEXT
 #undef B3_TCOL
 #undef B3_VPLANE

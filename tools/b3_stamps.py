@@ -50,6 +50,7 @@ def main():
         print("   " + "  ".join(f"{NAMES[i]} {t[:, i].mean():.0f}" for i in (5, 0, 1, 2, 3, 4)))
         print(f"   per tile: start {t[:, 0].mean() / tiles:.1f}  last step {t[:, 2].mean() / tiles:.1f}  epilogue {t[:, 3].mean() / tiles:.1f}  switch {t[:, 4].mean() / tiles:.1f}"
               f"   per full step: {t[:, 1].mean() / max(steps, 1):.1f} = phases " + " ".join(f"{t[:, i].mean() / max(steps, 1):.1f}" for i in (8, 9, 10, 11)) + f" + barrier {t[:, 12].mean() / max(steps, 1):.1f}")
+        print(f"   epilogue per tile: write halves + barriers {t[:, 13].mean() / tiles:.1f}  reads + stores {t[:, 14].mean() / tiles:.1f}  zeroing {t[:, 15].mean() / tiles:.1f}  rest {t[:, 3].mean() / tiles:.1f}")
         lib.pivlfn_conv_destroy(h)
 
 
