@@ -120,6 +120,14 @@ int pivlfn_forward(pivlfn_net *net, const float *img1, const float *img2, float 
 #define PIVLFN_PRECISION_F32 0
 #define PIVLFN_PRECISION_F16 1
 #define PIVLFN_PRECISION_F32_DIRECT 4
+/* PIVLFN_PRECISION_F32_WINO_MFMA32: the default of rounds 3-5 -- as PIVLFN_PRECISION_F32, but every Winograd layer on the fp32 matrix
+ * instruction (csrc/conv_wino.hip).  Since round 6 PIVLFN_PRECISION_F32 runs the Winograd layers with whole 64-channel output groups
+ * and >= 64 staged input channels on csrc/conv_wino_b3.hip: the same algorithm and the same fp32 U = G g G^T, each fp32 operand split
+ * EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, fp32's exponent range: no narrower input domain) and each product
+ * formed from six exact bf16 x bf16 products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 -- what is dropped is <= 2^-23 of a
+ * product (2^-26 typically), below the rounding of an fp32 fma; measured against float64 the layer error is at or below both
+ * fp32-instruction kernels' (tests/test_gpu_wino_b3.py). */
+#define PIVLFN_PRECISION_F32_WINO_MFMA32 5
 /* PIVLFN_PRECISION_F32_SPLIT: fp32 results from the fp16 matrix cores.  Every fp32 operand is split exactly into three fp16
  * pieces (11 + 11 + 2 significand bits at scales 1, 2^-11, 2^-22) and each product is formed from six exact fp16 x fp16
  * products accumulated in fp32; what is dropped is below 2^-32 of a product, 256 x under the rounding of an fp32 fma

@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     do {                                                                                          \
         const int scl_ = p.seg[lseg].cload;                                                       \
         const __amdgpu_buffer_rsrc_t rs_ = lseg == 0 ? rsv[0] : (lseg == 1 ? rsv[1] : rsv[2]);    \
-        const bool qok_ = lc0 + q4 < scl_;                                                        \
+        const bool qok_ = lc0 + q4 < scl_ B3_ABL_PATCHCOND;                                       \
         _Pragma("unroll") for (int s = 0; s < BPS; ++s)                                           \
-            PR[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? (s ? pvo_base + (unsigned)(s * lrstep) : pvo_first) : WOOB), lc0 * 4, 0)); \
+            PR[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? B3_ABL_NEAR(s ? pvo_base + (unsigned)(s * lrstep) : pvo_first) : WOOB), lc0 * 4, 0)); \
         lc0 += 16;                                                                                \
         if (lc0 >= scl_ && lseg + 1 < p.nseg) {                                                   \
             ++lseg;                                                                               \
@@ -261,6 +261,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 // what the compiler makes of any wait while an LDS-DMA is in flight anyway.  Under the phase's MFMAs the next plane's operand pieces
 // are produced and the next step's columns replace the current ones as they die; phase 0 also sends the patch of the step after next
 // on its way to LDS.  WNEXT = byte offset of the next step's weight fragments.
+#ifdef B3_ABL_NOPATCH       // timing build: every patch load out of range (zeros, no memory access)
+#define B3_ABL_PATCHCOND && p.H < 0
+#else
+#define B3_ABL_PATCHCOND
+#endif
+#ifdef B3_ABL_PATCHNEAR     // timing build: every patch load inside the first 16 KB of its descriptor (cache hits, data still random)
+#define B3_ABL_NEAR(V) ((V) >= WOOB ? WOOB : ((V) & 0x3ff0u) + (unsigned)lrstep)      /* three rows below the descriptor base: inside the image */
+#else
+#define B3_ABL_NEAR(V) (V)
+#endif
 #ifndef B3_PHASED
 #define B3_PHASED 0
 #endif
@@ -276,8 +286,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_STEP(WNEXT)                                                                         \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
-        B3_LOADP(pr);                                                                             \
         B3_ULOAD(woff, 3, 1);                                                                     \
+        B3_LOADP(pr);       /* behind the fragment loads: the in-order vmcnt then forces the patch two phases from here, not one */ \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                        \
         B3_TCOL(0, bo1);                                                                          \
@@ -311,8 +321,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_STEP_LAST(WNEXT)                                                                       \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
-        B3_LOADP(pr);                                                                             \
         B3_ULOAD(woff, 3, 1);                                                                     \
+        B3_LOADP(pr);       /* behind the fragment loads: the in-order vmcnt then forces the patch two phases from here, not one */ \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                    \
         B3_WAITVM();                                                                              \
@@ -422,6 +432,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + orow * p.out_stride, 0,
             (unsigned)min(((size_t)(p.H - y0) * p.W) * p.out_stride * 4, (size_t)0x7fffffff), 0x00020000);
         const int ox = x0 + 2 * rts + qq;
+#ifdef B3_ABL_NOEPI      // timing build: no output transform at all
+        if (p.H < 0)
+#endif
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             if (mb) __syncthreads();            // the first half has been read
@@ -455,7 +468,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
                     }
                     const int oyl = 2 * (mb * 4 + k) + pp;
                     const bool ok = y0 + oyl < p.H && ox < p.W && ch < p.cout_store;
+#ifdef B3_ABL_NOSTORE      // timing build: every store out of range (dropped by the range check)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok && p.H < 0 ? (unsigned)((oyl * p.W + ox) * p.out_stride + ch) * 4u : WOOB), 0, 0);
+#else
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok ? (unsigned)((oyl * p.W + ox) * p.out_stride + ch) * 4u : WOOB), 0, 0);
+#endif
                 }
             }
             BSTAMP(14);

@@ -645,6 +645,7 @@ size_t net_levels_floats(const pivlfn_net *net, int B, int H, int W)
 }
 
 static thread_local int t_precision = 0;      // set by net_forward for the duration of one forward
+static thread_local bool t_no_b3 = false;      // PIVLFN_PRECISION_F32_WINO_MFMA32: t_precision 0 with every Winograd layer on the fp32 instruction
 static thread_local float *t_scratch = nullptr;          // split-K scratch of the forward in progress (main stream only)
 static thread_local hipStream_t t_side = nullptr;
 
@@ -707,9 +708,24 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         (long)Ho * Wo >= (PIV_KNOB(12) ? PIV_KNOB(12) : 64 * 64) && cout_store % 4 == 0) {
         ConvParamsW q;
         memset(&q, 0, sizeof(q));
-        int i = 0;
-        for (auto &sg : segs) q.seg[i++] = sg;
+        int i = 0, cl = 0;
+        for (auto &sg : segs) { q.seg[i++] = sg; cl += sg.cload; }
         q.nseg = i;
+        // Default fp32 mode: layers with whole 64-channel output groups and at least 64 staged input channels run the same Winograd
+        // algorithm with every operand split exactly into three bf16 pieces on the 16-bit matrix cores (conv_wino_b3.hip; all 24
+        // significand bits, error against float64 at or below the fp32 instruction's: tests/test_gpu_wino_b3.py) -- 1.03-1.25 x the
+        // speed of the fp32-instruction kernel on those layers at 256^2 ... 1024^2; narrower inputs (conv_M.0: 49 channels) and the 32-
+        // and 96-channel layers stay on conv_wino.hip.  Per layer shape, never per batch.  PIVLFN_PRECISION_F32_WINO_MFMA32 keeps
+        // every layer on the fp32 instruction.
+        // From 256 x 256 outputs per image: its persistent workgroups (one per CU, 16 x 16 pixels x 64 channels per tile) need at least a
+        // tile per CU; the 128 x 128 layers of level 4 took 23-64 us on it against 12-25 us on conv_wino.hip.
+        if (!t_no_b3 && cw.wpk_wb && conv_wino_b3_supports(cw.cout_pad) && cl >= 64 && (long)Ho * Wo >= 256 * 256 && !(PIV_KNOB(1) & 2097152) &&
+            (long)16 * W * out_stride * 4 < (1L << 31)) {
+            q.wpk_b = cw.wpk_wb; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
+            q.cout_pad = cw.cout_pad;
+            q.B = B; q.H = H; q.W = W; q.nchunk = cw.nstep_wb; q.lrelu = lrelu; q.terms = 6;
+            return launch_conv_wb(q, st);
+        }
         q.wpk = cw.wpk_w; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
         q.cout_pad = cw.cout_pad;
         q.B = B; q.H = H; q.W = W; q.nchunk = cw.nchunk_w; q.lrelu = lrelu;
@@ -741,7 +757,7 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
 
 int net_set_precision(pivlfn_net *net, int precision)
 {
-    PIV_REQUIRE(net && precision >= 0 && precision <= 4, "set_precision: 0 (fp32 instruction), 1 (fp16 multiplicands), 2 (fp32 by exact splitting), 3 (three-term splitting) or 4 (fp32 instruction, direct convolution only) expected");
+    PIV_REQUIRE(net && precision >= 0 && precision <= 5, "set_precision: 0 (fp32: Winograd with exactly split operands / fp32 instruction), 1 (fp16 multiplicands), 2 (fp32 by exact fp16 splitting), 3 (three-term splitting), 4 (fp32 instruction, direct convolution only) or 5 (fp32 instruction, Winograd) expected");
     net->precision = precision;
     return PIVLFN_OK;
 }
@@ -820,6 +836,7 @@ int conv_forward_cat(const pivlfn_conv *c, int nsrc, const float *const *x, cons
         sg[i] = ConvSeg{x[i], rup(c->src_real[i], 4), x_stride[i]};
     }
     t_precision = 0;
+    t_no_b3 = false;
     t_side = nullptr;
     t_scratch = nullptr;          // never split: the handle has no per-batch scratch
     const int cs = std::min(rup(c->cw.cout, 4), y_stride);
@@ -880,7 +897,8 @@ int net_forward(pivlfn_net *net, const float *img1, const float *img2, float *fl
     PIV_REQUIRE(B > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
                 "forward: H=%d W=%d must be positive multiples of 32 (use estimate() for other sizes)", H, W);
     PIV_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "forward: workspace must be 256-byte aligned");
-    t_precision = net->precision;
+    t_precision = net->precision == 5 ? 0 : net->precision;
+    t_no_b3 = net->precision == 5;
     t_side = net->side;
     Plan pl; Buffers bf;
     pl.base = reinterpret_cast<char *>(ws);

@@ -87,13 +87,17 @@ class LiteFlowNet(torch.nn.Module):
         self._precision = "fp32"
 
     # -- precision of the conv stacks ---------------------------------------------------------------------
-    _PRECISIONS = {"fp32": 0, "fp16": 1, "fp32_split": 2, "fp32_split3": 3, "fp32_direct": 4}
+    _PRECISIONS = {"fp32": 0, "fp16": 1, "fp32_split": 2, "fp32_split3": 3, "fp32_direct": 4, "fp32_wino_mfma32": 5}
 
     @property
     def precision(self) -> str:
         """How the large convolutions multiply (everything else -- correlation, warps, heads, small levels -- is fp32 throughout):
-        'fp32'        (default) the fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32: fp32 operands, exact fp32 fma chains);
-                      the 3x3 stride-1 layers by Winograd F(2x2, 3x3) in fp32 (csrc/conv_wino.hip), the rest by direct convolution;
+        'fp32'        (default) fp32 operands (all 24 bits), fp32 products and accumulation.  The 3x3 stride-1 layers by Winograd F(2x2, 3x3):
+                      those with whole 64-channel output groups and >= 64 input channels with every operand split exactly into three
+                      bf16 pieces on v_mfma_f32_32x32x16_bf16 (csrc/conv_wino_b3.hip: six exact piece products per product, what is
+                      dropped is <= 2^-23 of it; fp32's input domain), the others on the fp32 matrix-core instruction
+                      v_mfma_f32_32x32x2_f32 (csrc/conv_wino.hip); every other layer by direct convolution on that instruction;
+        'fp32_wino_mfma32' the default of rounds 3-5: as 'fp32' with every Winograd layer on the fp32 instruction;
         'fp32_direct' the same instruction, direct convolution for every layer (2.25 x the multiplies of 'fp32' in the 3x3 layers);
         'fp32_split'  fp32 operands as three fp16 pieces each (all 24 bits), six partial products on the fp16 matrix cores, fp32
                       accumulation: products exact to 2^-32 (csrc/conv_split.hip); inputs of those layers must stay below 65504;
@@ -104,7 +108,7 @@ class LiteFlowNet(torch.nn.Module):
     @precision.setter
     def precision(self, value: str) -> None:
         if value not in self._PRECISIONS:
-            raise ValueError("precision must be 'fp32', 'fp32_direct', 'fp32_split', 'fp32_split3' or 'fp16'")
+            raise ValueError("precision must be 'fp32', 'fp32_wino_mfma32', 'fp32_direct', 'fp32_split', 'fp32_split3' or 'fp16'")
         self._precision = value
         if self.__dict__.get("_handle") is not None:
             _lib.check(_lib.load().pivlfn_set_precision(self._handle, self._PRECISIONS[value]), "set_precision")
