@@ -115,19 +115,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     // 256 threads carry a record.  A thread's global offset is then ONE value + s x (3 image rows) and its LDS offset one of TWO values
     // (even / odd slots: the de-interleaved row order) + a constant: 4 registers where a slot table takes 12 (which the register allocator
     // spilled, and a spill reload waits vmcnt(0) -- for the patch loads in flight and for the epilogue's stores).
-    const int q4 = (tid & 3) * 4;
-    const int spix = tid >> 2, sr = spix >= 54 ? 3 : (spix >= 36 ? 2 : (spix >= 18 ? 1 : 0)), spx = spix - 18 * sr;
-    const int scol = sr < 3 ? ((spx >> 1) + (spx & 1) * 9) * BPIXQ + (tid & 3) : 90 + (tid & 3);      // idle threads: the padding at the end of a row
-    const int plds_even = (sr < 3 ? ((sr >> 1) + (sr & 1) * 9) * BROWQ : 0) + scol;
-    const int plds_odd = (sr < 3 ? (((sr + 1) >> 1) + (1 - (sr & 1)) * 9) * BROWQ : 0) + scol;
+    // These per-lane addresses are recomputed at every tile start from a laundered thread id (B3_LANE_ADDRS): as loop invariants they
+    // would be live across the epilogue, which wants the registers -- the allocator spilled four of them per tile.
+    int plds_even, plds_odd, abase[2];
     // plane row i = wave: (B^T d)[i][.] = d[ra][.] + sb * d[rb][.]
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sb = wave == 1 ? 1.f : -1.f;
-    int abase[2];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-        abase[mb] = (mb * 4 + (n >> 3) + (ra >> 1) + (ra & 1) * (BPH / 2)) * BROWQ + (n & 7) * BPIXQ + 2 * g;      // patch pixel (2 tyl + ra, 2 txl), quads 2 g, 2 g + 1
+#define B3_LANE_ADDRS()                                                                           \
+    do {                                                                                          \
+        int tl_ = tid;                                                                            \
+        asm volatile("" : "+v"(tl_));                                                             \
+        const int spix_ = tl_ >> 2, sr_ = spix_ >= 54 ? 3 : (spix_ >= 36 ? 2 : (spix_ >= 18 ? 1 : 0)), spx_ = spix_ - 18 * sr_; \
+        const int scol_ = sr_ < 3 ? ((spx_ >> 1) + (spx_ & 1) * 9) * BPIXQ + (tl_ & 3) : 90 + (tl_ & 3);      /* idle threads: the padding at the end of a row */ \
+        plds_even = (sr_ < 3 ? ((sr_ >> 1) + (sr_ & 1) * 9) * BROWQ : 0) + scol_;                 \
+        plds_odd = (sr_ < 3 ? (((sr_ + 1) >> 1) + (1 - (sr_ & 1)) * 9) * BROWQ : 0) + scol_;      \
+        const int n_ = tl_ & 31, g_ = (tl_ >> 5) & 1;                                             \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                          \
+            abase[mb] = (mb * 4 + (n_ >> 3) + (ra >> 1) + (ra & 1) * (BPH / 2)) * BROWQ + (n_ & 7) * BPIXQ + 2 * g_;      /* patch pixel (2 tyl + ra, 2 txl), quads 2 g, 2 g + 1 */ \
+    } while (0)
     const int abdiff = (((rb >> 1) + (rb & 1) * (BPH / 2)) - ((ra >> 1) + (ra & 1) * (BPH / 2))) * BROWQ;             // row rb from row ra (wave-uniform)
 
     // (starting a tile's accumulators from the constant 0 in its first MFMAs, as conv_wino.hip does, costs a second copy of the step
@@ -150,6 +156,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     // ---- the load stream: (tile, step) whose patch is fetched next, two steps ahead of the matrix work and across tile boundaries
     const size_t img_px = (size_t)p.H * p.W;
     int ltile = ctile, lseg = 0, lc0 = 0, ly0 = 0, lx0 = 0, lrow0 = 0;
+    // tile coordinates without divisions in the loop: (channel group, tile column, tile row, image) of the load stream, advanced by the
+    // decomposed stride with carries; the tile being multiplied is the one the load stream left at its last B3_LNEXT
+    int lng = ctile % NG, ltx = (ctile / NG) % tiles_x, lty = (ctile / NG / tiles_x) % tiles_y, lb = ctile / NG / tiles_x / tiles_y;
+    const int dng = tstride % NG, dtx = (tstride / NG) % tiles_x, dty = (tstride / NG / tiles_x) % tiles_y, db = tstride / NG / tiles_x / tiles_y;
+    int cng = lng, cx0 = ltx * 16, cy0 = lty * 16, cb = lb;
     __amdgpu_buffer_rsrc_t rsv[3];
     // byte offset of the thread's record in slot 1..5 (+ s x lrstep) and in slot 0, inside the load tile's current source (the descriptor
     // starts one row above the tile: at the patch's first row); WOOB = none (left / right / top padding, idle thread); rows below the image
@@ -170,11 +181,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 // the patch rows only
 #define B3_LTILE()                                                                                \
     do {                                                                                          \
-        int t_ = ltile / NG;                                                                      \
-        lx0 = (t_ % tiles_x) * 16;                                                                \
-        t_ /= tiles_x;                                                                            \
-        ly0 = (t_ % tiles_y) * 16;                                                                \
-        const int lb_ = t_ / tiles_y;                                                             \
+        lx0 = ltx * 16;                                                                           \
+        ly0 = lty * 16;                                                                           \
+        const int lb_ = lb;                                                                       \
         lrow0 = ly0 - 1;                                                                          \
         _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                           \
             const int ss = s < p.nseg ? s : 0;                                                    \
@@ -187,19 +196,35 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     } while (0)
 // patch of the load stream's step -> PR, then advance the stream inside its tile (the loads and this rare branch sit at the top of a
 // step: everything behind them is one basic block).  The stream changes tiles in ONE place, B3_LNEXT, two steps before the matrix work does.
-#define B3_LOADP(PR)                                                                              \
+#if B3_BRANCHFREE     // the source switch as selects + an unconditional B3_PVO: the whole step is one basic block
+#define B3_ADVANCE_SEG(SCL)                                                                       \
     do {                                                                                          \
-        const int scl_ = p.seg[lseg].cload;                                                       \
-        const __amdgpu_buffer_rsrc_t rs_ = lseg == 0 ? rsv[0] : (lseg == 1 ? rsv[1] : rsv[2]);    \
-        const bool qok_ = lc0 + q4 < scl_ B3_ABL_PATCHCOND;                                       \
-        _Pragma("unroll") for (int s = 0; s < BPS; ++s)                                           \
-            PR[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? B3_ABL_NEAR(s ? pvo_base + (unsigned)(s * lrstep) : pvo_first) : WOOB), lc0 * 4, 0)); \
-        lc0 += 16;                                                                                \
-        if (lc0 >= scl_ && lseg + 1 < p.nseg) {                                                   \
+        const bool sw_ = lc0 >= (SCL) && lseg + 1 < p.nseg;                                       \
+        lseg += sw_ ? 1 : 0;                                                                      \
+        lc0 = sw_ ? 0 : lc0;                                                                      \
+        B3_PVO(lseg);                                                                             \
+    } while (0)
+#else
+#define B3_ADVANCE_SEG(SCL)                                                                       \
+    do {                                                                                          \
+        if (lc0 >= (SCL) && lseg + 1 < p.nseg) {                                                  \
             ++lseg;                                                                               \
             lc0 = 0;                                                                              \
             B3_PVO(lseg);                                                                         \
         }                                                                                         \
+    } while (0)
+#endif
+#define B3_LOADP(PR)                                                                              \
+    do {                                                                                          \
+        const int scl_ = p.seg[lseg].cload;                                                       \
+        const __amdgpu_buffer_rsrc_t rs_ = lseg == 0 ? rsv[0] : (lseg == 1 ? rsv[1] : rsv[2]);    \
+        int tq_ = tid;                                                                            \
+        asm volatile("" : "+v"(tq_));       /* (tid & 3) * 4 kept as a loop invariant was the one register the allocator still spilled */ \
+        const bool qok_ = lc0 + (tq_ & 3) * 4 < scl_ B3_ABL_PATCHCOND;                            \
+        _Pragma("unroll") for (int s = 0; s < BPS; ++s)                                           \
+            PR[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(qok_ ? B3_ABL_NEAR(s ? pvo_base + (unsigned)(s * lrstep) : pvo_first) : WOOB), lc0 * 4, 0)); \
+        lc0 += 16;                                                                                \
+        B3_ADVANCE_SEG(scl_);                                                                     \
     } while (0)
 #define B3_COMMIT(PR, BOFF)                                                                       \
     do {                                                                                          \
@@ -209,8 +234,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 // the load stream moves on to this workgroup's next tile (past the last one: every slot out of range -- zeros, no memory access)
 #define B3_LNEXT()                                                                                \
     do {                                                                                          \
+        cng = lng; cx0 = lx0; cy0 = ly0; cb = lb;                                                 \
         ltile += tstride;                                                                         \
         if (ltile < tend) {                                                                       \
+            lng += dng;                                                                           \
+            if (lng >= NG) { lng -= NG; ++ltx; }                                                  \
+            ltx += dtx;                                                                           \
+            if (ltx >= tiles_x) { ltx -= tiles_x; ++lty; }                                        \
+            lty += dty;                                                                           \
+            if (lty >= tiles_y) { lty -= tiles_y; ++lb; }                                         \
+            lb += db;                                                                             \
             B3_LTILE();                                                                           \
         } else {                                                                                  \
             lseg = 0; lc0 = 0;                                                                    \
@@ -242,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_ULOAD(WOFF, J, SLOT)                                                                   \
     do {                                                                                          \
         _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) \
-            U[SLOT][nb][pc] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane + pc * 1024, (WOFF) + (J)*6144 + nb * 3072, 0)); \
+            U[SLOT][nb][pc] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane + pc * 1024, B3_ABL_UOFF((WOFF) + (J)*6144) + nb * 3072, 0)); \
     } while (0)
 #define B3_ONE(J, SLOT, WP, XP)                                                                   \
     _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
@@ -271,6 +304,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #else
 #define B3_ABL_NEAR(V) (V)
 #endif
+#ifdef B3_ABL_UNEAR         // timing build: every weight-fragment load from this wave's first 6 KB (L1 hits, data still random)
+#define B3_ABL_UOFF(V) (wave * BWAVE * 16)
+#else
+#define B3_ABL_UOFF(V) (V)
+#endif
+#ifndef B3_PATCH_LATE
+#define B3_PATCH_LATE 0
+#endif
+#ifndef B3_BRANCHFREE
+#define B3_BRANCHFREE 0
+#endif
+#ifndef B3_ZERO_EARLY
+#define B3_ZERO_EARLY 1
+#endif
+#ifndef B3_XTILE
+#define B3_XTILE 0
+#endif
+#ifndef B3_KB
+#define B3_KB 4      // tile rows whose exchange reads are in flight together in the epilogue
+#endif
 #ifndef B3_PHASED
 #define B3_PHASED 0
 #endif
@@ -283,11 +336,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #else
 #define B3_WAITVM() do { } while (0)
 #endif
+#if B3_PATCH_LATE      // the patch loads behind the phase's fragment loads: the in-order vmcnt then forces them two phases from here, not one
+#define B3_STEP_HEAD()                                                                            \
+    do {                                                                                          \
+        B3_ULOAD(woff, 3, 1);                                                                     \
+        B3_LOADP(pr);                                                                             \
+    } while (0)
+#else
+#define B3_STEP_HEAD()                                                                            \
+    do {                                                                                          \
+        B3_LOADP(pr);                                                                             \
+        B3_ULOAD(woff, 3, 1);                                                                     \
+    } while (0)
+#endif
 #define B3_STEP(WNEXT)                                                                         \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
-        B3_ULOAD(woff, 3, 1);                                                                     \
-        B3_LOADP(pr);       /* behind the fragment loads: the in-order vmcnt then forces the patch two phases from here, not one */ \
+        B3_STEP_HEAD();                                                                           \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                        \
         B3_TCOL(0, bo1);                                                                          \
@@ -321,8 +386,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_STEP_LAST(WNEXT)                                                                       \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
-        B3_ULOAD(woff, 3, 1);                                                                     \
-        B3_LOADP(pr);       /* behind the fragment loads: the in-order vmcnt then forces the patch two phases from here, not one */ \
+        B3_STEP_HEAD();                                                                           \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                    \
         B3_WAITVM();                                                                              \
@@ -363,6 +427,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     f32x4 t[2][4][2];               // [tile block][patch column][quad]: row-combined columns of the current step
     u32x4 V[2][2][3], U[2][2][3];   // [slot][tile block | channel block][piece]
     int bo1 = BBUF_A, bo2 = BBUF_B; // the image read during a step (the NEXT step's patch) and the buffer the step after next is committed to
+    B3_LANE_ADDRS();
     B3_LTILE();
     // prologue: the first two patches of the stream and the first weight fragments in flight together
     {
@@ -377,15 +442,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 
     // p.nchunk >= 2 (launcher).  The load stream is two steps ahead: entering a tile it stands at the tile's third step, and it moves on
     // to the next tile in front of the tile's last but one step.
+#if B3_XTILE
+    B3_TCOL(0, bo2); B3_TCOL(1, bo2); B3_TCOL(2, bo2); B3_TCOL(3, bo2);
+    B3_VPLANE(0, 0);
+    __syncthreads();
+#endif
     for (;;) {
+#if !B3_XTILE
         // tile start: bo2 holds the tile's first image, bo1 its second
+        B3_LANE_ADDRS();
         B3_TCOL(0, bo2); B3_TCOL(1, bo2); B3_TCOL(2, bo2); B3_TCOL(3, bo2);
         B3_VPLANE(0, 0);
         __syncthreads();            // every wave has read the first image: its buffer is free for the tile's third step
+#endif
         BSTAMP(0);
         const int ntile = ctile + tstride;
-        // the step after a tile's last one is the next tile's first (past the last tile: the same fragments again, loaded and never used)
-        const int wfirst = ntile < tend ? ((ntile % NG) * 4 + wave) * BWAVE * 16 : woff;
         for (int c = 0; c + 1 < p.nchunk; ++c) {
             if (c == p.nchunk - 2) {
                 B3_LNEXT();
@@ -396,7 +467,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
             if (stamp_) { const unsigned long long ph_ = sd_[8] + sd_[9] + sd_[10] + sd_[11] + sd_[12]; sd_[1] = ph_; sd_[7] += 1; }
 #endif
         }
+        // the step after a tile's last one is the next tile's first: the load stream stands on that tile (past the last tile: the same
+        // fragments again, loaded and never used)
+        const int wfirst = ntile < tend ? (lng * 4 + wave) * BWAVE * 16 : woff;
+#if B3_XTILE
+        B3_STEP(wfirst);
+#else
         B3_STEP_LAST(wfirst);
+#endif
         BSTAMP(2);
         __builtin_amdgcn_sched_barrier(0);      // nothing of the epilogue is hoisted into the step (the first planes' accumulators are final early: their reads would be)
 
@@ -408,12 +486,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         // lines (a lane per tile and 16 bytes of it -- 64 lines per instruction -- took 4100 cycles per half); the XOR keeps the
         // writers' eight-lane groups on distinct banks.
         f32x4 *xch = smem4 + BXCH;
-        int t_ = ctile;
-        const int ng = t_ % NG;
-        t_ /= NG;
-        const int x0 = (t_ % tiles_x) * 16;
-        t_ /= tiles_x;
-        const int y0 = (t_ % tiles_y) * 16, b = t_ / tiles_y;
+        const int ng = cng, x0 = cx0, y0 = cy0, b = cb;
         const int pp = wave >> 1, qq = wave & 1;      // this wave finishes output pixel (pp, qq) of every tile
         // (the lane id is laundered per tile: left visible, the epilogue's per-lane addresses are loop invariants that the compiler keeps in
         //  registers through the K steps -- and spills; a spill reload waits vmcnt(0))
@@ -451,33 +524,54 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
                     xch[((nw * 4 + wave) * 2 + 0) * 256 + wq] = (m[0] + m[1]) + m[2];
                     xch[((nw * 4 + wave) * 2 + 1) * 256 + wq] = (m[1] - m[2]) - m[3];
                 }
+#if B3_ZERO_EARLY
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][mb][nb][r] = 0.f;       // this half's accumulators are read: zero them under the writes' latency
+#endif
             __syncthreads();
             BSTAMP(13 + 0 * mb);
+            // branch-free (the row pair is a wave-uniform offset and a sign), B3_KB tile rows' reads in flight together: with one wave per
+            // SIMD every LDS round trip that is waited for on its own is exposed
+            const float sg = pp ? -1.f : 1.f;
 #pragma unroll
             for (int nw = 0; nw < 2; ++nw) {
                 const int ch = (ng * 2 + nw) * 32 + 4 * rc4;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4 *x = xch + (nw * 4 * 2 + qq) * 256 + k * 64 + ln;     // wave i at x[i * 2 * 256]
-                    f32x4 y;
-                    if (pp == 0) y = (x[0] + x[1 * 512]) + x[2 * 512];
-                    else y = (x[1 * 512] - x[2 * 512]) - x[3 * 512];
-                    y += bias4[nw];
-                    if (p.lrelu) {
-                        y[0] = lrelu01(y[0]); y[1] = lrelu01(y[1]); y[2] = lrelu01(y[2]); y[3] = lrelu01(y[3]);
-                    }
-                    const int oyl = 2 * (mb * 4 + k) + pp;
-                    const bool ok = y0 + oyl < p.H && ox < p.W && ch < p.cout_store;
+                for (int k0 = 0; k0 < 4; k0 += B3_KB) {
+                    f32x4 xv[B3_KB][3];
+#pragma unroll
+                    for (int kk = 0; kk < B3_KB; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) xv[kk][i] = xch[((nw * 4 + pp + i) * 2 + qq) * 256 + (k0 + kk) * 64 + ln];
+#pragma unroll
+                    for (int kk = 0; kk < B3_KB; ++kk) {
+                        const int k = k0 + kk;
+                        f32x4 y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // pp = 0: (R_0 + R_1) + R_2;  pp = 1: (R_1 - R_2) - R_3  (sg * x is exact)
+                            const float v = __builtin_fmaf(sg, xv[kk][2][e], __builtin_fmaf(sg, xv[kk][1][e], xv[kk][0][e])) + bias4[nw][e];
+                            y[e] = p.lrelu ? lrelu01(v) : v;
+                        }
+                        const int oyl = 2 * (mb * 4 + k) + pp;
+                        const bool ok = y0 + oyl < p.H && ox < p.W && ch < p.cout_store;
 #ifdef B3_ABL_NOSTORE      // timing build: every store out of range (dropped by the range check)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok && p.H < 0 ? (unsigned)((oyl * p.W + ox) * p.out_stride + ch) * 4u : WOOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok && p.H < 0 ? (unsigned)((oyl * p.W + ox) * p.out_stride + ch) * 4u : WOOB), 0, 0);
 #else
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok ? (unsigned)((oyl * p.W + ox) * p.out_stride + ch) * 4u : WOOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ors, (int)(ok ? (unsigned)((oyl * p.W + ox) * p.out_stride + ch) * 4u : WOOB), 0, 0);
 #endif
+                    }
                 }
             }
             BSTAMP(14);
         }
+#if !B3_ZERO_EARLY
         B3_ZERO_ACC();
+#endif
         BSTAMP(15);
         BSTAMP(3);
 #ifdef PIVLFN_STAMPS
@@ -494,6 +588,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #endif
 #undef BSTAMP
 #undef B3_PVO
+#undef B3_LANE_ADDRS
 #undef B3_LTILE
 #undef B3_LOADP
 #undef B3_COMMIT
