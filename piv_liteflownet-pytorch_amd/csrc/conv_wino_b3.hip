@@ -299,8 +299,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #else
 #define B3_ABL_PATCHCOND
 #endif
-#ifdef B3_ABL_PATCHNEAR     // timing build: every patch load inside the first 16 KB of its descriptor (cache hits, data still random)
-#define B3_ABL_NEAR(V) ((V) >= WOOB ? WOOB : ((V) & 0x3ff0u) + (unsigned)lrstep)      /* three rows below the descriptor base: inside the image */
+#ifdef B3_ABL_PATCHNEAR     // timing build: every patch load inside a small window of its descriptor (cache hits, data still random)
+#ifndef B3_ABL_NEARMASK
+#define B3_ABL_NEARMASK 0x3ff0u      // 16 KB: L1 hits; 0x1ffff0u = 2 MB: L2 hits
+#endif
+#define B3_ABL_NEAR(V) ((V) >= WOOB ? WOOB : ((V) & B3_ABL_NEARMASK) + (unsigned)lrstep)      /* three rows below the descriptor base: inside the image */
 #else
 #define B3_ABL_NEAR(V) (V)
 #endif
@@ -309,11 +312,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #else
 #define B3_ABL_UOFF(V) (V)
 #endif
-#ifndef B3_PATCH_LATE
-#define B3_PATCH_LATE 0
+#ifndef B3_PATCH_POS
+#define B3_PATCH_POS 3      // behind the fragment loads of phase 2: -3 % against position 0 (tools/bench_b3.py, same box), no spill in any instance
 #endif
 #ifndef B3_BRANCHFREE
-#define B3_BRANCHFREE 0
+#define B3_BRANCHFREE 1
 #endif
 #ifndef B3_ZERO_EARLY
 #define B3_ZERO_EARLY 1
@@ -336,35 +339,32 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #else
 #define B3_WAITVM() do { } while (0)
 #endif
-#if B3_PATCH_LATE      // the patch loads behind the phase's fragment loads: the in-order vmcnt then forces them two phases from here, not one
-#define B3_STEP_HEAD()                                                                            \
+// Where in a step the patch loads are issued: 0 = in front of the first fragment loads (one phase until the in-order vmcnt forces them),
+// 1 / 2 / 3 = behind the fragment loads of phase 0 / 1 / 2 (two phases)
+#define B3_PATCH_AT(POS)                                                                          \
     do {                                                                                          \
-        B3_ULOAD(woff, 3, 1);                                                                     \
-        B3_LOADP(pr);                                                                             \
+        if (B3_PATCH_POS == (POS)) B3_LOADP(pr);                                                  \
     } while (0)
-#else
-#define B3_STEP_HEAD()                                                                            \
-    do {                                                                                          \
-        B3_LOADP(pr);                                                                             \
-        B3_ULOAD(woff, 3, 1);                                                                     \
-    } while (0)
-#endif
 #define B3_STEP(WNEXT)                                                                         \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
-        B3_STEP_HEAD();                                                                           \
+        B3_PATCH_AT(0);                                                                           \
+        B3_ULOAD(woff, 3, 1);                                                                     \
+        B3_PATCH_AT(1);                                                                           \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                        \
         B3_TCOL(0, bo1);                                                                          \
         BSTAMP(8);                                                                                \
         B3_WAITVM();                                                                              \
         B3_ULOAD(woff, 1, 0);                                                                     \
+        B3_PATCH_AT(2);                                                                           \
         B3_VPLANE(1, 0);                                                                          \
         B3_MFMAS(3, 1);                                                                        \
         B3_TCOL(3, bo1);                                                                          \
         BSTAMP(9);                                                                                \
         B3_WAITVM();                                                                              \
         B3_ULOAD(woff, 2, 1);                                                                     \
+        B3_PATCH_AT(3);                                                                           \
         B3_VPLANE(2, 1);                                                                          \
         B3_MFMAS(1, 0);                                                                        \
         B3_TCOL(1, bo1);                                                                          \
@@ -386,15 +386,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_STEP_LAST(WNEXT)                                                                       \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
-        B3_STEP_HEAD();                                                                           \
+        B3_PATCH_AT(0);                                                                           \
+        B3_ULOAD(woff, 3, 1);                                                                     \
+        B3_PATCH_AT(1);                                                                           \
         B3_VPLANE(3, 1);                                                                          \
         B3_MFMAS(0, 0);                                                                    \
         B3_WAITVM();                                                                              \
         B3_ULOAD(woff, 1, 0);                                                                     \
+        B3_PATCH_AT(2);                                                                           \
         B3_VPLANE(1, 0);                                                                          \
         B3_MFMAS(3, 1);                                                                    \
         B3_WAITVM();                                                                              \
         B3_ULOAD(woff, 2, 1);                                                                     \
+        B3_PATCH_AT(3);                                                                           \
         B3_VPLANE(2, 1);                                                                          \
         B3_MFMAS(1, 0);                                                                    \
         B3_WAITVM();                                                                              \
