@@ -292,31 +292,73 @@ def l3_throughput_regime(dev, batch=8, launches=40):
 
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without an outer launcher: start N fresh ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_* set, one device each), relay rank 0's output and return non-zero when a rank fails.  The parent makes no GPU call --
-    torch.cuda.device_count() does not initialise the device on this image -- and never re-executes itself."""
+    MASTER_* set, one device each), relay rank 0's output and SUPERVISE them: every rank is polled; when one exits non-zero the others
+    are terminated (then killed), the dead rank is named with the tail of its stderr and the parent returns non-zero within seconds;
+    an overall deadline (PIVLFN_BENCH_DEADLINE_S, default 1500 s) bounds the whole run.  The parent makes no GPU call and never
+    re-executes itself or a rank: a failed run is reported, not retried."""
     import socket
     import subprocess
+    import tempfile
+    import threading
     backend = os.environ.get("PIVLFN_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
+    ndev = torch.cuda.device_count()      # (counting devices does not initialise one on this image; nothing below depends on that)
     if backend == "nccl" and ndev < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but {ndev} device(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    deadline = time.monotonic() + float(os.environ.get("PIVLFN_BENCH_DEADLINE_S", "1500"))
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        errs.append(tempfile.TemporaryFile(mode="w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
-    sys.stdout.write(out0)
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r], text=True))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout), daemon=True)      # rank 0's stdout never blocks on a full pipe
+    reader.start()
+
+    def tail(r, n=12):
+        errs[r].seek(0)
+        return "".join(errs[r].readlines()[-n:])
+
+    def stop_all():
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t_kill = time.monotonic() + 5.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
+    failed = None
+    while True:
+        rcs = [q.poll() for q in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}" + (f" (also: {bad[1:]})" if len(bad) > 1 else "")
+            dead = bad[0][0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed, dead = "deadline passed with ranks still running: " + str([r for r, rc in enumerate(rcs) if rc is None]), None
+            break
+        time.sleep(0.2)
+    if failed:
+        stop_all()
+    reader.join(timeout=5.0)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    if failed:
+        print(f"bench.py: {failed}; the other ranks were stopped", file=sys.stderr)
+        for r in ([dead] if dead is not None else range(args.gpus)):
+            print(f"--- stderr tail of rank {r} ---\n{tail(r)}", file=sys.stderr)
         return 1
     return 0
 
@@ -330,6 +372,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if os.environ.get("PIVLFN_BENCH_FAIL_RANK") == str(rank):      # test knob: this rank dies before the rendezvous
+        print(f"bench.py: rank {rank} exits 3 on request (PIVLFN_BENCH_FAIL_RANK)", file=sys.stderr)
+        sys.exit(3)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     backend = os.environ.get("PIVLFN_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 control flow on a 1-GPU box
     if backend != "nccl":
@@ -341,12 +386,14 @@ def main():
     # RCCL branch this way on the one-GPU box); MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE must then be set by the caller
     use_dist = world > 1 or os.environ.get("PIVLFN_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tmo = datetime.timedelta(seconds=float(os.environ.get("PIVLFN_BENCH_INIT_TIMEOUT_S", "120")))      # a missing rank is reported, not waited for
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)  # nccl == RCCL on ROCm
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     import pivlfn
     from pivlfn import synth
@@ -406,15 +453,21 @@ def main():
     k_ms, k_empty_ms, k_n = net.profile_read() if L else (0.0, 0.0, 0)
     if L:
         net.profile_enable(0)
-    per_rank = [{"rank": 0, "pairs_per_s": round(args.steps * B / t_own, 3), "gather_wait_ms_per_step": 0.0}]
+    devname = torch.cuda.get_device_name(dev)
+    per_rank = [{"rank": 0, "pairs_per_s": round(args.steps * B / t_own, 3), "gather_wait_ms_per_step": 0.0, "device_index": local, "device_name": devname}]
+    backend_world = 1
     if use_dist:
+        backend_world = dist.get_world_size()       # what the backend saw, not what the launcher asked for
         t = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         mine = torch.tensor([args.steps * B / t_own, wait_s[0] / args.steps * 1e3], device=gdev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "pairs_per_s": round(float(v[0]), 3), "gather_wait_ms_per_step": round(float(v[1]), 4)} for r, v in enumerate(allr)]
+        who = [None] * world
+        dist.all_gather_object(who, (local, devname))
+        per_rank = [{"rank": r, "pairs_per_s": round(float(v[0]), 3), "gather_wait_ms_per_step": round(float(v[1]), 4),
+                     "device_index": who[r][0], "device_name": who[r][1]} for r, v in enumerate(allr)]
     # level-1 launch of the same kernel family (395 MB: beyond the 256 MiB Infinity Cache), timed the same way in a few extra steps
     l1 = None
     if L == 3 and world == 1 and args.model == "piv" and args.size == 1024 and net.lowest_level == 1 and not args.lean:
@@ -480,6 +533,7 @@ def main():
                           "hbm_frac_of_8tbs": round(value / world * 16.57 / 8000.0, 4) if (args.model == 'piv' and S == 1024) else None},
         }
         out["per_rank"] = per_rank
+        out["backend_world_size"] = backend_world
         if l1 is not None and l1[2]:
             alg1 = l3_algorithmic_bytes(B, S, S, 1, 64, 2)
             t1 = l1[0] / l1[2] * 1e-3

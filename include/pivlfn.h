@@ -35,7 +35,7 @@ typedef struct {
 } pivlfn_tensor;
 
 const char *pivlfn_last_error(void);
-/* ABI version.  3 (round 6): + pivlfn_conv2d_nhwc_wino_b3, PIVLFN_PRECISION_F32_WINO_MFMA32.  2 (round 4): + pivlfn_warp_corr_nhwc_timed, pivlfn_conv2d_nhwc_wino4, pivlfn_conv_create_cat, pivlfn_conv2d_nhwc_cat; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
+/* ABI version.  3 (round 6): + pivlfn_conv2d_nhwc_wino_b3, PIVLFN_PRECISION_F32_WINO_MFMA32; - pivlfn_conv2d_nhwc_wino4 (now exported by the tools build only).  2 (round 4): + pivlfn_warp_corr_nhwc_timed, pivlfn_conv2d_nhwc_wino4, pivlfn_conv_create_cat, pivlfn_conv2d_nhwc_cat; since 1 also pivlfn_conv2d_nhwc_wino and PIVLFN_PRECISION_F32_DIRECT
  * (added in round 3 without a bump).  No entry point of version 1 changed its signature or meaning. */
 int         pivlfn_abi_version(void);
 
@@ -185,10 +185,13 @@ int pivlfn_conv2d_nhwc_wino(const pivlfn_conv *conv, const float *x, int x_strid
  * (<= 2^-32) or 9 (the exact product of the two fp32 operands).  fp32 x, fp32 y. */
 int pivlfn_conv2d_nhwc_wino_b3(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                                int B, int H, int W, int leaky, int terms, void *stream);
-/* The same layer on the Winograd F(4x4, 3x3) kernel (6 x 6 transforms; relative error ~1e-5 against ~1.4e-6 of F(2x2)).  Measured
- * and kept as an entry point only: pivlfn_forward does not use it (0.98x of F(2x2) on 128->128 at 1024 x 1024, slower below). */
+#ifdef PIVLFN_TOOLS
+/* Tools build only (tools/libpivlfn_tools.so; the kernel lives in tools/kernels/conv_wino4.hip since round 6): the same layer on the
+ * Winograd F(4x4, 3x3) kernel (6 x 6 transforms; relative error ~1e-5 against ~1.4e-6 of F(2x2)).  Measured 0.98x of F(2x2) on
+ * 128->128 at 1024 x 1024 and slower below: no user path launches it. */
 int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                              int B, int H, int W, int leaky, void *stream);
+#endif
 
 /* One Conv2d (odd k, stride 1, "same" padding, + bias, optional LeakyReLU(0.1)) over the channel concatenation of 1-3 sources --
  * torch.cat + Conv2d of the front layers of Matching / Subpixel / Regularization (src/models.py:171-187, 209-217, 280) -- through

@@ -192,11 +192,13 @@ int pivlfn_conv2d_nhwc_wino_b3(const pivlfn_conv *conv, const float *x, int x_st
     return conv_forward_wb(conv, x, x_stride, y, y_stride, B, H, W, leaky, terms, (hipStream_t)stream);
 }
 
+#ifdef PIVLFN_TOOLS
 int pivlfn_conv2d_nhwc_wino4(const pivlfn_conv *conv, const float *x, int x_stride, float *y, int y_stride,
                              int B, int H, int W, int leaky, void *stream)
 {
     return conv_forward_w(conv, x, x_stride, y, y_stride, B, H, W, leaky, (hipStream_t)stream, 4);
 }
+#endif
 
 int pivlfn_conv_create_cat(const float *weight, const float *bias, int cout, int nsrc, const int *channels, int kh, int kw, pivlfn_conv **out)
 {

@@ -5,9 +5,9 @@
 #                     stamps); only tools/*.py load it
 set -e
 cd "$(dirname "$0")"
-SRCS="conv_mfma conv_wino conv_wino_b3 conv_wino4 conv_f16 conv_split conv_head warp_corr corr_bwd ops net api"
-build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags, $4 = extra sources
-  local OBJ="$1" OUT="$2" SRCS="$SRCS $4"
+SRCS="conv_mfma conv_wino conv_wino_b3 conv_f16 conv_split conv_head warp_corr corr_bwd ops net api"
+build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags, $4 = extra sources (research kernels of tools/kernels/)
+  local OBJ="$1" OUT="$2" EXTRA="$4"
   mkdir -p "$OBJ"
   local FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $3 $PIVLFN_EXTRA_FLAGS"
   # a change to any header (or to the flags) rebuilds everything: no stale objects
@@ -28,12 +28,20 @@ build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags, $4 = extra
       pids+=($!)
     fi
   done
+  for f in $EXTRA; do
+    objs+=("$OBJ/$f.o")
+    if [ ! -f "$OBJ/$f.o" ] || [ "../../tools/kernels/$f.hip" -nt "$OBJ/$f.o" ]; then
+      hipcc $FLAGS -I. -c "../../tools/kernels/$f.hip" -o "$OBJ/$f.o" &
+      pids+=($!)
+    fi
+  done
   for p in "${pids[@]}"; do wait "$p"; done
   hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
   echo "built $OUT"
 }
 build_one ../../build/obj ../pivlfn/libpivlfn.so ""
 if [ "$1" = "tools" ]; then
-  # conv_wino_ws: round 5's persistent Winograd kernel with specialised waves -- slower than conv_wino, kept for A/B runs only
-  build_one ../../build/obj_tools ../../tools/libpivlfn_tools.so "-DPIVLFN_TOOLS -DPIVLFN_STAMPS" "conv_wino_ws"
+  # research kernels that no user path launches (tools/kernels/): round 5's persistent Winograd kernel with specialised waves and round
+  # 4's F(4x4, 3x3) kernel -- both measured slower than conv_wino.hip, kept with their tests for A/B runs
+  build_one ../../build/obj_tools ../../tools/libpivlfn_tools.so "-DPIVLFN_TOOLS -DPIVLFN_STAMPS" "conv_wino_ws conv_wino4"
 fi

@@ -16,8 +16,12 @@ void set_error(const char *fmt, ...);
 #ifdef PIVLFN_TOOLS
 extern int g_knob[16];
 #define PIV_KNOB(i) (pivlfn::g_knob[i])
+#define PIV_DBG(p) ((p).dbg)            // a kernel's ablation mask (timing runs of the tools): a field of its parameter block
+#define PIV_SET_DBG(p, v) ((p).dbg = (v))
 #else
 #define PIV_KNOB(i) 0
+#define PIV_DBG(p) 0                    // production: the constant 0 -- no field in the parameter blocks, no test in the kernels
+#define PIV_SET_DBG(p, v) ((void)0)
 #endif
 
 // Opt-in to > 64 KiB of dynamic LDS for kernel `fn`, once per (call site, device); thread-safe.  `slot` is a zero-initialised
@@ -114,7 +118,9 @@ struct ConvParams {
     size_t scratch_floats;
     int ksplit;         // number of K shares (set by the launcher; 0/1 = no split)
     unsigned long long *stamps;   // tools only: per-workgroup phase times (s_memtime ticks), 8 per workgroup; nullptr in production
+#ifdef PIVLFN_TOOLS
     int dbg;            // tools only (-DPIVLFN_STAMPS builds): ablation mask, 1 no MFMAs, 2 no global loads, 4 no epilogue stores
+#endif
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);
@@ -148,7 +154,9 @@ struct ConvParamsH {
     int B, H, W, Ho, Wo;
     int KH, KW, S, padY, padX;
     int nchunk, lrelu;
+#ifdef PIVLFN_TOOLS
     int dbg;            // ablation mask for tools/bench_ops.py (0 in production): 1 no MFMAs, 2 no global loads, 4 no LDS commit
+#endif
     unsigned long long *stamps;   // tools only: per-workgroup phase times (s_memtime ticks), 8 per workgroup; nullptr in production
 };
 int launch_conv_h(const ConvParamsH &p, hipStream_t st);
@@ -171,7 +179,9 @@ struct ConvParamsX {
     int B, H, W, Ho, Wo;
     int KH, KW, S, padY, padX;
     int nchunk, lrelu;
+#ifdef PIVLFN_TOOLS
     int dbg;            // ablation mask for tools/bench_ops.py (0 in production): 1 no MFMAs, 2 no global loads, 4 no LDS commit
+#endif
 };
 int launch_conv_x(const ConvParamsX &p, hipStream_t st);
 bool conv_split_supports(int KH, int KW, int S, int cout_pad, int terms);
@@ -186,7 +196,9 @@ struct ConvParamsW {
     int B, H, W;        // output grid = input grid (3x3, stride 1, pad 1)
     int nchunk, lrelu;
     unsigned long long *stamps;   // tools build (-DPIVLFN_STAMPS) only: per-workgroup phase times of wave 0 (s_memtime ticks), 8 per workgroup; nullptr in production
+#ifdef PIVLFN_TOOLS
     int dbg;            // tools build only: ablation mask of conv_wino_ws.hip (timing runs, wrong results)
+#endif
     const void *wpk_b;  // conv_wino_b3.hip: the same U split into three bf16 pieces, [nchunk][cout_pad/64][4][4][2][3][64][8] (pack_conv_wb); nchunk = K steps of 16 channels
     int terms;          // conv_wino_b3.hip: piece products per product, 6 (default), 8 or 9
 };

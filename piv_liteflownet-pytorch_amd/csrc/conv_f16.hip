@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
 #define CH_LOAD(CH)                                                                               \
     do {                                                                                          \
         ld_f16 = sf16;                                                                            \
-        if (p.dbg & 2) break;                                                                     \
+        if (PIV_DBG(p) & 2) break;                                                                     \
         if (sf16) {                                                                               \
             const bool ok_ = c0 + 8 * sub < scl;                                                  \
             _Pragma("unroll") for (int i = 0; i < PM; ++i) {                                      \
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
     CH_LOAD(0);
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         // registers -> LDS (waits for this chunk's loads), converting fp32 sources to fp16
-        if (p.dbg & 4) {
+        if (PIV_DBG(p) & 4) {
         } else if (ld_f16) {
 #pragma unroll
             for (int i = 0; i < PM; ++i)
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
                     *reinterpret_cast<h4 *>(d + 8) = h4{(_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
                 }
         }
-        if (!(p.dbg & 4)) {
+        if (!(PIV_DBG(p) & 4)) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
                 if (tid + 256 * i < nw) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, (MT * NT * 16 + (2 * PM + WM) * 4 + 60 > 240) 
         }
         STAMP(d_issue);
         int tap = 0;
-        for (int ky = 0; ky < ((p.dbg & 1) ? 0 : p.KH); ++ky) {
+        for (int ky = 0; ky < ((PIV_DBG(p) & 1) ? 0 : p.KH); ++ky) {
             for (int kx = 0; kx < p.KW; ++kx, ++tap) {
                 const int toff = (ky * PW + kx) * HPITCH;
                 h8 a[MT], wq[NT];
@@ -290,7 +290,7 @@ static int launch_h(const ConvParamsH &p, hipStream_t st)
 int launch_conv_h(const ConvParamsH &p_in, hipStream_t st)
 {
     ConvParamsH p = p_in;
-    p.dbg = PIV_KNOB(3);
+    PIV_SET_DBG(p, PIV_KNOB(3));
     p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.nchunk >= 1, "conv_f16: bad segment description");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0, "conv_f16: bad output channel counts");

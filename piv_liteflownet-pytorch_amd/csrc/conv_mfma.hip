@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 4 && NT <= 2 && PMAX <= 5) ? 3 : 2
     for (int i = 0; i < PMAX; ++i) pvo[i] = ppix[i] != C2OOB ? ppix[i] * (unsigned)(sst * 4) + (unsigned)q4 * 4u : C2OOB;
 
 #ifdef PIVLFN_STAMPS
-#define CONV2_ABL(BIT) (p.dbg & (BIT))
+#define CONV2_ABL(BIT) (PIV_DBG(p) & (BIT))
 #else
 #define CONV2_ABL(BIT) false
 #endif
@@ -983,7 +983,7 @@ static int launch_conv2(const ConvParams &p_in, hipStream_t st)
 {
     ConvParams p = p_in;
     p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only
-    p.dbg = PIV_KNOB(7);
+    PIV_SET_DBG(p, PIV_KNOB(7));
     const int taps = p.KH * p.KW;
     for (int s = 0; s < p.nseg; ++s)      // 32-bit byte offsets inside the rows of one patch (the descriptors are rebased per workgroup)
         PIV_REQUIRE((size_t)(15 * p.S + p.KH) * p.W * p.seg[s].stride * 4 < 0x7fffffffull, "conv: one patch (%d rows x %d x %d floats) of source %d exceeds the 2 GiB buffer-descriptor range", 15 * p.S + p.KH, p.W, p.seg[s].stride, s);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
 
 #define X_LOAD_PATCH()                                                                            \
     do {                                                                                          \
-        if (p.dbg & 2) break;                                                                     \
+        if (PIV_DBG(p) & 2) break;                                                                     \
         const bool ok0_ = c0 + 4 * sub < scl, ok1_ = c0 + 8 + 4 * sub < scl;                      \
         _Pragma("unroll") for (int i = 0; i < PM; ++i) {                                          \
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};                           \
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
     } while (0)
 #define X_LOAD_W(ROWIDX)                                                                          \
     do {                                                                                          \
-        if (p.dbg & 2) break;                                                                     \
+        if (PIV_DBG(p) & 2) break;                                                                     \
         const f32x4 *wc_ = wsrc + (size_t)(ROWIDX)*wrow;                                          \
         _Pragma("unroll") for (int i = 0; i < WM; ++i) {                                          \
             const int idx_ = tid + 256 * i;                                                       \
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // registers -> LDS: split this chunk's fp32 patch into its three fp16 pieces (the previous chunk's last barrier has
         // been passed by every wave: the patch buffer is free)
-        if (!(p.dbg & 4)) {
+        if (!(PIV_DBG(p) & 4)) {
 #pragma unroll
             for (int i = 0; i < PM; ++i)
                 if (poff[i] != -2) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
                 }
         }
         for (int ky = 0; ky < p.KH; ++ky, ++phase) {
-            if (!(p.dbg & 4)) {
+            if (!(PIV_DBG(p) & 4)) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
                     if (tid + 256 * i < nw) reinterpret_cast<f32x4 *>(wts)[tid + 256 * i] = wr[i];
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, OCC) void conv_split_kernel(const ConvParamsX 
                 X_LOAD_PATCH();
             }
             if (phase + 1 < nrows) X_LOAD_W(phase + 1);
-            if (!(p.dbg & 1)) {
+            if (!(PIV_DBG(p) & 1)) {
                 for (int kx = 0; kx < p.KW; ++kx) {
                     const int toff = (ky * PW + kx) * XPITCH;
                     h8 a[MT][NP];
@@ -650,7 +650,7 @@ bool conv_split_supports(int KH, int KW, int S, int cout_pad, int terms)
 int launch_conv_x(const ConvParamsX &p_in, hipStream_t st)
 {
     ConvParamsX p = p_in;
-    p.dbg = PIV_KNOB(3);
+    PIV_SET_DBG(p, PIV_KNOB(3));
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.nchunk >= 1, "conv_split: bad segment description");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0, "conv_split: bad output channel counts");
     for (int i = 0; i < p.nseg; ++i)

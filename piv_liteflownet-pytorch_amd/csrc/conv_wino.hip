@@ -441,7 +441,7 @@ int launch_conv_w(const ConvParamsW &p_in, hipStream_t st)
 {
     ConvParamsW p = p_in;
     p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(6) << 32) | (unsigned)PIV_KNOB(5));   // tools only (0 in production)
-    p.dbg = PIV_KNOB(15);
+    PIV_SET_DBG(p, PIV_KNOB(15));
     PIV_REQUIRE(p.nseg >= 1 && p.nseg <= 3 && p.wpk && p.bias && p.out, "conv_wino: bad arguments");
     PIV_REQUIRE(p.cout_pad % 32 == 0 && p.cout_store <= p.cout_pad && p.cout_store % 4 == 0 && p.out_stride % 4 == 0,
                 "conv_wino: cout_pad=%d cout_store=%d out_stride=%d", p.cout_pad, p.cout_store, p.out_stride);

@@ -26,8 +26,10 @@ void pack_conv_x(const float *w, int cout, int cin, int taps, const int *creal, 
 void pack_conv_x_tail(const float *w, int cout, int cin, int c_first, int c_real, float scale_inv, std::vector<unsigned short> &pk);
 void pack_conv_w(const float *w, int cout, int cin, const int *creal, const int *cload, const int *coff, int nseg,
                  std::vector<float> &pk, int *nchunk_out);
+#ifdef PIVLFN_TOOLS
 void pack_conv_w4(const float *w, int cout, int cin, const int *creal, const int *cload, const int *coff, int nseg,
-                 std::vector<float> &pk, int *nchunk_out);      // conv_wino.hip
+                 std::vector<float> &pk, int *nchunk_out);      // tools/kernels/conv_wino4.hip
+#endif
 void pack_conv_wb(const float *w, int cout, int cin, const int *creal, const int *cload, const int *coff, int nseg,
                   std::vector<unsigned short> &pk, int *nstep_out);      // conv_wino_b3.hip
 
@@ -84,8 +86,6 @@ struct pivlfn_net {
     pivlfn::ConvW ext[3];          // index by level (1,2)
     pivlfn::LevelW lv[7];
     std::vector<void *> allocs;
-    bool pack_w4 = false;          // also pack the F(4x4, 3x3) Winograd weights of 3 x 3 layers: the owner of a stand-alone layer object
-                                   // (pivlfn_conv2d_nhwc_wino4 needs them); a network never launches that kernel
     // side stream for the flow-independent 1x1 convs (NetC_ext, moduleFeat): they overlap the latency-bound coarse levels
     hipStream_t side = nullptr;
     float *fuse1_w = nullptr, *fuse1_b = nullptr;      // level 1: NetC_ext + moduleFeat as 1 x 1 layers inside NetC.conv1's kernel (Conv1Fuse)
@@ -224,15 +224,10 @@ static int pack_conv(pivlfn_net *net, const TMap &m, const std::string &name, in
         // F(4x4): 2.25 x the F(2x2) planes per layer -- only where something can launch it (round 4 packed and uploaded it for every
         // 3 x 3 layer of every network although pivlfn_forward never reaches that kernel outside the tools build's knob 13)
 #ifdef PIVLFN_TOOLS
-        const bool w4 = true;
-#else
-        const bool w4 = net->pack_w4;
+        pack_conv_w4(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w4);
+        rc = upload(net, pw, &out->wpk_w4);
+        if (rc) return rc;
 #endif
-        if (w4) {
-            pack_conv_w4(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pw, &out->nchunk_w4);
-            rc = upload(net, pw, &out->wpk_w4);
-            if (rc) return rc;
-        }
         if (conv_wino_b3_supports(cp)) {
             std::vector<unsigned short> pb;
             pack_conv_wb(w->data, cout, cin, cr.data(), cl.data(), co.data(), (int)segs.size(), pb, &out->nstep_wb);
@@ -494,7 +489,6 @@ int conv_create(const float *weight, const float *bias, int cout, int cin, int k
     m["c.bias"] = &t[1];
     pivlfn_conv *c = new pivlfn_conv();
     c->owner = new pivlfn_net();
-    c->owner->pack_w4 = true;
     c->cin = cin;
     int rc = pack_conv(c->owner, m, "c", cout, cin, kh, kw, {{cin, rup(cin, 4)}}, &c->cw);
     if (!rc && cout == 2 && cin == 32 && kh == kw && (kh == 3 || kh == 5 || kh == 7)) rc = pack_head(c->owner, m, "c", kh, &c->head, c->hb);
@@ -732,10 +726,12 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         // F(4x4, 3x3) is not used by pivlfn_forward: 1.78x fewer matrix instructions, but its 6x6 transforms, 106 KB of LDS (one
         // workgroup per CU) and lockstep of 12 waves leave it at 0.98x of F(2x2) on 128->128 and 0.68x on 32->32 at 1024 x 1024
         // (DESIGN.md 4.2c).  The tools build can switch it in from knob 13 output pixels per image up, for A/B runs of the forward.
+#ifdef PIVLFN_TOOLS
         if (cw.wpk_w4 && PIV_KNOB(13) > 0 && (long)Ho * Wo >= PIV_KNOB(13)) {
             q.wpk = cw.wpk_w4; q.nchunk = cw.nchunk_w4;
             return launch_conv_w4(q, st);
         }
+#endif
         return launch_conv_w(q, st);
     }
     ConvParams p;
@@ -864,9 +860,13 @@ int conv_forward_w(const pivlfn_conv *c, const float *x, int x_stride, float *y,
     q.cout_pad = c->cw.cout_pad;
     q.B = B; q.H = H; q.W = W; q.nchunk = c->cw.nchunk_w; q.lrelu = leaky;
     if (tile == 4) {
+#ifdef PIVLFN_TOOLS
         PIV_REQUIRE(c->cw.wpk_w4, "conv2d_wino4: the layer object carries no F(4x4) weights");
         q.wpk = c->cw.wpk_w4; q.nchunk = c->cw.nchunk_w4;
         return launch_conv_w4(q, st);
+#else
+        PIV_REQUIRE(false, "conv2d_wino: the F(4x4) kernel is part of the tools build only");
+#endif
     }
     return launch_conv_w(q, st);
 }

@@ -44,7 +44,9 @@ struct WcParams {
     float *out;
     float scale;
     int B, C, H, W, s, Ho, Wo, leaky;
+#ifdef PIVLFN_TOOLS
     int dbg;      // ablation mask for tools/bench_ops.py (0 in production): 1 skip dot products, 2 skip gathers, 4 skip store, 8 exit at entry
+#endif
     int strips;   // 1: walk the tiles in strips of 8 tile rows, column by column (wide images; see warp_corr_v3_kernel)
     int rl;       // v6: run length (vertically consecutive tiles per run), set by its launcher
     unsigned long long *stamps;   // tools build only: per-workgroup phase stamps (16 u64 per record, 2 records per workgroup); nullptr in production
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
         b = bid / tiles_y;
     }
     const int ox0 = tx * TO, oy0 = ty * TO;
-    if (p.dbg & 8) return;
+    if (PIV_DBG(p) & 8) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id, provably uniform
     const size_t img = (size_t)p.H * p.W;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
 #define WC3_ISSUE(X, XF, XR, CB)                                                                  \
     do {                                                                                          \
         const unsigned cb_ = (unsigned)(CB)*128u + 16u * q8;                                      \
-        if (p.dbg & 2) {   /* ablation: no memory traffic */                                      \
+        if (PIV_DBG(p) & 2) {   /* ablation: no memory traffic */                                      \
             _Pragma("unroll") for (int u = 0; u < 3; ++u)                                         \
                 _Pragma("unroll") for (int k = 0; k < NT; ++k) X[u][k] = f32x4{1.f, 2.f, 3.f, 4.f}; \
             XR = f32x4{1.f, 2.f, 3.f, 4.f};                                                       \
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
         WC3_COMMIT(xa, fa, ra, buf, (buf + NPOS * PP));            // waits for chunk c's loads, blends, writes LDS buffer c&1
         if (c + 1 < nch) WC3_ISSUE(xa, fa, ra, c + 1);             // next chunk in flight during the dot products below
         __syncthreads();     // buffer c&1 complete; every wave is past the dot products on buffer (c+1)&1
-        if (!(p.dbg & 1)) {
+        if (!(PIV_DBG(p) & 1)) {
             if constexpr (R2) WC3_DOTS_R2(buf, (buf + NPOS * PP));
             else WC3_DOTS(buf, (buf + NPOS * PP));
         }
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(512, 4) void warp_corr_v3_kernel(const WcParams p)
     for (int idx = tid; idx < 64 * (OUTC / 4); idx += 512) {
         const int pp = idx / (OUTC / 4), q = idx - pp * (OUTC / 4);
         const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
-        if (oy < p.Ho && ox < p.Wo && !(p.dbg & 4))
+        if (oy < p.Ho && ox < p.Wo && !(PIV_DBG(p) & 4))
             *reinterpret_cast<f32x4 *>(p.out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * OUTC + 4 * q) =
                 *reinterpret_cast<const f32x4 *>(ost + pp * OUTC + 4 * q);
     }
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int ox0 = tx * TO, oy0 = ty * TO;
-    if (p.dbg & 8) return;
+    if (PIV_DBG(p) & 8) return;
     WC_STAMP_DECL;
     WC_STAMP();                                   // 0: entry
     const int tid = threadIdx.x, lane = tid & 63;
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     for (int c0 = 0; c0 < p.C; c0 += 64) {
         const unsigned cb = (unsigned)c0 * 4u + 16u * q16;
         f32x4 x[3][NT], xr;
-        if (p.dbg & 2) {
+        if (PIV_DBG(p) & 2) {
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
         __syncthreads();
         WC_STAMP();                                   // 5: barrier 2 passed
 
-        if (!(p.dbg & 1)) {
+        if (!(PIV_DBG(p) & 1)) {
             int lane_l = lane;
             asm volatile("" : "+v"(lane_l));      // opaque per chunk: keeps the 64 LDS read addresses from being hoisted out of the loop
             const int ppx = lane_l & 7, ppy = lane_l >> 3;
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v4_kernel(const WcParams p)
     }
     __syncthreads();
     WC_STAMP();                                   // 8: transposed, barrier 4 passed
-    if (tid < 64 * (OUTC / 4) && !(p.dbg & 4)) {
+    if (tid < 64 * (OUTC / 4) && !(PIV_DBG(p) & 4)) {
         const int pp = tid / (OUTC / 4), q = tid - pp * (OUTC / 4);
         const int oy = oy0 + (pp >> 3), ox = ox0 + (pp & 7);
         if (oy < p.Ho && ox < p.Wo)
@@ -1038,7 +1040,7 @@ __device__ __forceinline__ void k6_reduce(const K6Acc &A, int lane, float (&r2)[
 #ifdef PIVLFN_STAMPS
 #define K6_STAMP(role, idx)                                                                        \
     do {                                                                                           \
-        if (p.stamps && (p.dbg & 32) && lane == 0 && (unsigned)(idx) < 96u) p.stamps[((size_t)blockIdx.x * 4 + (role)) * 96 + (idx)] = __builtin_amdgcn_s_memtime(); \
+        if (p.stamps && (PIV_DBG(p) & 32) && lane == 0 && (unsigned)(idx) < 96u) p.stamps[((size_t)blockIdx.x * 4 + (role)) * 96 + (idx)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define K6_STAMP(role, idx) do { } while (0)
@@ -1073,7 +1075,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
         S.nruns = w < cnt ? (cnt - w + nw - 1) / nw : 0;
         S.r0 = base + w; S.rstep = nw;
     }
-    if (S.nruns == 0 || (p.dbg & 8)) return;
+    if (S.nruns == 0 || (PIV_DBG(p) & 8)) return;
     const int nch = p.C >> 5;                      // 32-channel chunks per tile (>= 2, checked by the launcher)
     const size_t img = (size_t)p.H * p.W;
     const unsigned img_bytes = (unsigned)(img * p.C * sizeof(float));
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
                 __syncthreads();
                 if (wave == 0) K6_STAMP(0, 3 * m);
                 const unsigned bo = (m & 1) ? (unsigned)K6_BUF : 0u;
-                if (work && !(p.dbg & 1)) {
+                if (work && !(PIV_DBG(p) & 1)) {
                     unsigned row[10];
 #pragma unroll
                     for (int r = 0; r < 10; ++r) row[r] = rowoff[r] + bo;
@@ -1212,7 +1214,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
             const int item = min(tpl + 512 * u, 64 * (OUTC / 4) - 1);
             const int px = item / (OUTC / 4), q = item - px * (OUTC / 4);
             const int oy = t.oy0 + (px >> 3), ox = t.ox0 + (px & 7);
-            const bool ok = on & (tpl + 512 * u < 64 * (OUTC / 4)) & (oy < p.Ho) & (ox < p.Wo) & !(p.dbg & 4);      // & not &&: no short-circuit branches
+            const bool ok = on & (tpl + 512 * u < 64 * (OUTC / 4)) & (oy < p.Ho) & (ox < p.Wo) & !(PIV_DBG(p) & 4);      // & not &&: no short-circuit branches
             const unsigned off = ok ? (unsigned)((oy * p.Wo + ox) * OUTC + 4 * q) * 4u : OOB;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(tr + px * OUTC + 4 * q);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rso, (int)off, 0, 0);
@@ -1262,7 +1264,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the table entries this wave wrote are read back below
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        issue_item(tp, u, *reinterpret_cast<const i32x4 *>(lds + tof[u]), dst[u], rs2, 0, !(p.dbg & 2));
+        issue_item(tp, u, *reinterpret_cast<const i32x4 *>(lds + tof[u]), dst[u], rs2, 0, !(PIV_DBG(p) & 2));
         __builtin_amdgcn_sched_barrier(0);         // item order = the phases' order: the wait counts at the loop head merge both paths
     }
     // A tile's chunks are walked as code instances (first / middle / last chunk  x  items of this tile  x  items of the next tile):
@@ -1283,7 +1285,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v6_kernel(const WcParams p)
         if constexpr (FIRST && HASFLOW) fl = tap_flow(Tn);
         const unsigned bufbase = (m & 1) ? (unsigned)K6_BUF : 0u;
         const int soff = LAST ? 0 : (k + 1) * 128;
-        const bool valid = (!LAST || has_next) && !(p.dbg & 2);      // dbg & 2 (tools): every gather out of range -- issued, no data moved
+        const bool valid = (!LAST || has_next) && !(PIV_DBG(p) & 2);      // dbg & 2 (tools): every gather out of range -- issued, no data moved
         unsigned dstn[NS], tofn[NS];                // the next unit's item parameters (last phase: its loads go out here)
         if constexpr (LAST) slot_params(tpl, Tn, dstn, tofn);
         const unsigned (&tfi)[NS] = LAST ? tofn : tof;
@@ -1405,7 +1407,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v7_kernel(const WcParams p)
     bid /= tiles_x;
     const int ty = bid % tiles_y, b = bid / tiles_y;
     const int ox0 = tx * TO, oy0 = ty * TO;
-    if (p.dbg & 8) return;
+    if (PIV_DBG(p) & 8) return;
     WC_STAMP_DECL;
     WC_STAMP();                                   // 0: entry
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1460,7 +1462,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v7_kernel(const WcParams p)
             if (u < 3 || has3) {
                 const int pos = min(pq + 64 * u, NPOS - 1);
                 const i32x4 o = *reinterpret_cast<const i32x4 *>(lds + K7_TAPS + pos * 32);
-                const bool ok = (pq + 64 * u < NPOS) & !(p.dbg & 2);
+                const bool ok = (pq + 64 * u < NPOS) & !(PIV_DBG(p) & 2);
 #pragma unroll
                 for (int k = 0; k < NT; ++k) x[u][k] = bload_s(rs2, ok ? (unsigned)o[k] + 16u * q16 : OOB, soff);
             }
@@ -1489,7 +1491,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v7_kernel(const WcParams p)
         WC_STAMP();                                   // 4: gathers arrived, blended, in LDS
         __syncthreads();
         WC_STAMP();                                   // 5: barrier passed
-        if (wave < 7 && !(p.dbg & 1)) {
+        if (wave < 7 && !(PIV_DBG(p) & 1)) {
             int ll = lane;
             asm volatile("" : "+v"(ll));           // the ten row addresses are built here, not kept across the gathers
             const int g_ = ll & 3, j_ = (ll >> 2) & 7, h_ = ll >> 5;
@@ -1516,7 +1518,7 @@ __global__ __launch_bounds__(1024) void warp_corr_v7_kernel(const WcParams p)
     WC_STAMP();                                   // 7: reduced, transposed
     __syncthreads();
     WC_STAMP();                                   // 8: barrier passed
-    if (tid < 64 * (OUTC / 4) && !(p.dbg & 4)) {
+    if (tid < 64 * (OUTC / 4) && !(PIV_DBG(p) & 4)) {
         const int px = tid / (OUTC / 4), q = tid - px * (OUTC / 4);
         const int oy = oy0 + (px >> 3), ox = ox0 + (px & 7);
         f32x4 v;
@@ -1555,8 +1557,12 @@ int launch_warp_corr(const float *f1, const float *f2, const float *flow, float 
     PIV_REQUIRE(f1 && f2 && out, "warp_corr: null pointer");
     PIV_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "warp_corr: empty shape B=%d C=%d H=%d W=%d", B, C, H, W);
     PIV_REQUIRE(stride >= 1 && stride <= 4, "warp_corr: stride=%d unsupported", stride);
-    WcParams p{f1, f2, flow, out, flow_scale, B, C, H, W, stride, cdiv(H, stride), cdiv(W, stride), leaky, PIV_KNOB(2), 0, 1,
-               reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(10) << 32) | (unsigned)PIV_KNOB(9))};
+    WcParams p{};
+    p.f1 = f1; p.f2 = f2; p.flow = flow; p.out = out; p.scale = flow_scale;
+    p.B = B; p.C = C; p.H = H; p.W = W; p.s = stride; p.Ho = cdiv(H, stride); p.Wo = cdiv(W, stride); p.leaky = leaky;
+    PIV_SET_DBG(p, PIV_KNOB(2));
+    p.strips = 0; p.rl = 1;
+    p.stamps = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)PIV_KNOB(10) << 32) | (unsigned)PIV_KNOB(9));
     if (nhwc) {
         PIV_REQUIRE(C % 32 == 0, "warp_corr (channels-last): C=%d must be a multiple of 32", C);
         // f2 rows under one row of tiles: beyond half an XCD's L2 the row-major walk loses the halo rows between tile rows

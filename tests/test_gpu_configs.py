@@ -215,9 +215,29 @@ def test_bench_py_starts_its_own_ranks(dev):
     assert len(lines) == 1
     j = lines[0]
     assert j["n_gpus"] == 2 and len(j["per_rank"]) == 2 and j["value"] > 0
+    # what the backend saw, and where every rank ran
+    assert j["backend_world_size"] == 2
+    assert all("device_index" in e and e["device_name"] for e in j["per_rank"])
     if torch.cuda.device_count() < 2:
         r = subprocess.run(cmd, env=dict(env, PIVLFN_BENCH_BACKEND="nccl"), capture_output=True, text=True, timeout=120)
         assert r.returncode != 0 and "device(s) visible" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_py_supervises_its_ranks(dev):
+    """A rank that dies before the rendezvous (PIVLFN_BENCH_FAIL_RANK=1: rank 1 exits 3) does not leave rank 0 sitting in
+    init_process_group: the parent notices, stops the other rank, names the dead one with its stderr and returns non-zero within
+    seconds -- no JSON line, no retry."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256", "--no-cpu-baseline",
+           "--no-arithmetic", "--lean"]
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, env=dict(env, PIVLFN_BENCH_BACKEND="gloo", PIVLFN_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    took = time.monotonic() - t0
+    assert r.returncode != 0
+    assert took < 30, took
+    assert "rank 1 exited with code 3" in r.stderr and "exits 3 on request" in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{") and "metric" in ln]
 
 
 def test_rccl_branch_executes_on_one_rank(dev, tmp_path):

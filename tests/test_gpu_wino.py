@@ -13,6 +13,28 @@ from test_gpu_conv import Conv, run as run_direct
 pytestmark = pytest.mark.gpu
 
 
+def _tools():
+    """tools/libpivlfn_tools.so: the research kernels of tools/kernels/ (F(4x4), the wave-specialised kernel) are compiled into it only."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import _toolslib
+    return _toolslib.load()
+
+
+class ToolsConv:
+    """A layer object of the tools library (its handles are not the production library's: other fields, F(4x4) weights packed)."""
+    def __init__(self, w, b):
+        import ctypes
+        self.w, self.b = w.contiguous(), b.contiguous()
+        self.h = ctypes.c_void_p()
+        co, ci, kh, kw = w.shape
+        assert _tools().pivlfn_conv_create(self.w.data_ptr(), self.b.data_ptr(), co, ci, kh, kw, ctypes.byref(self.h)) == 0
+
+    def __del__(self):
+        _tools().pivlfn_conv_destroy(self.h)
+
+
 def run_wino(conv, x_nchw, leaky, dev, x_lanes=None, y_lanes=None, tile=2):
     B, C, H, W = x_nchw.shape
     co = conv.w.shape[0]
@@ -22,8 +44,12 @@ def run_wino(conv, x_nchw, leaky, dev, x_lanes=None, y_lanes=None, tile=2):
     x = x.to(dev)
     ys = y_lanes or -(-co // 4) * 4
     y = torch.full((B, H, W, ys), float("nan"), device=dev)
-    fn = _lib.load().pivlfn_conv2d_nhwc_wino if tile == 2 else _lib.load().pivlfn_conv2d_nhwc_wino4
-    _lib.check(fn(conv.h, x.data_ptr(), xs, y.data_ptr(), ys, B, H, W, int(leaky), torch.cuda.current_stream(dev).cuda_stream), "conv2d_wino")
+    if tile == 2:
+        _lib.check(_lib.load().pivlfn_conv2d_nhwc_wino(conv.h, x.data_ptr(), xs, y.data_ptr(), ys, B, H, W, int(leaky), torch.cuda.current_stream(dev).cuda_stream), "conv2d_wino")
+    else:
+        assert isinstance(conv, ToolsConv)
+        rc = _tools().pivlfn_conv2d_nhwc_wino4(conv.h, x.data_ptr(), xs, y.data_ptr(), ys, B, H, W, int(leaky), torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0, _tools().pivlfn_last_error()
     y = y.cpu()
     cs = min(-(-co // 4) * 4, ys)
     assert torch.all(y[..., co:cs] == 0)            # padding lanes are exact zeros
@@ -75,8 +101,8 @@ def test_wino_matches_float64_conv(case, dev):
 
 @pytest.mark.parametrize("case", CASES)
 def test_wino4_matches_float64_conv(case, dev):
-    """The F(4x4, 3x3) kernel (csrc/conv_wino4.hip: an entry point of its own, pivlfn_conv2d_nhwc_wino4 -- pivlfn_forward never
-    launches it) on the same shapes:
+    """The F(4x4, 3x3) kernel (tools/kernels/conv_wino4.hip, compiled into the tools library only since round 6: no user path launches
+    it) on the same shapes:
     its transforms multiply by 2, 4, 5 and 8, so a layer's error against float64 is ~8e-6 of max |out| where F(2x2) and the direct
     kernel stay below 5e-7 (measured on the CPU restatement before the kernel existed: DESIGN.md 4.2c); the per-layer bound here is
     3e-5, and what decides is the end-to-end bound every oracle test holds the network to (1e-4 of the flow scale)."""
@@ -85,7 +111,7 @@ def test_wino4_matches_float64_conv(case, dev):
     w = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
     b = torch.randn(co, generator=g) * 0.1
     x = torch.randn(B, ci, H, W, generator=g)
-    conv = Conv(w, b)
+    conv = ToolsConv(w, b)
     for leaky in (False, True):
         want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
         if leaky:
@@ -208,3 +234,51 @@ def test_concatenated_sources_match_float64_conv(case, dev):
         assert err < 1e-5 * max(1.0, want.abs().max().item()), (case, err)
     finally:
         lib.pivlfn_conv_destroy(h)
+
+
+WS_CASES = [
+    # cout, cin (per source), H, W, B -- the shapes the bench never covered: ragged tiles, several images, 4-channel tail chunks, an odd
+    # number of channel blocks, two and three sources
+    (64, (64,), 37, 45, 2),
+    (128, (36,), 70, 130, 1),          # cin % 8 == 4
+    (96, (40,), 33, 47, 3),            # three channel blocks: one block per wave
+    (128, (64, 64, 4), 50, 66, 1),     # conv_S.0's three sources
+    (128, (128, 4), 41, 39, 2),        # conv_R.0's two sources
+    (32, (32,), 128, 160, 1),
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_wave_specialised_kernel_is_bit_identical(case, dev):
+    """tools/kernels/conv_wino_ws.hip (round 5: persistent workgroups, producer / consumer waves; slower than conv_wino.hip, kept in the
+    tools library for A/B runs) returns the shipped kernel's bits -- same packed weights, same summation order -- on ragged images,
+    several images, 4-channel tail chunks, odd channel-block counts and multi-source layers."""
+    import ctypes
+    lib = _tools()
+    co, cins, H, W, B = case
+    g = torch.Generator().manual_seed(co + sum(cins) + H)
+    ci = sum(cins)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).contiguous()
+    b = torch.randn(co, generator=g).contiguous()
+    h = ctypes.c_void_p()
+    ch = (ctypes.c_int * len(cins))(*cins)
+    assert lib.pivlfn_conv_create_cat(w.data_ptr(), b.data_ptr(), co, len(cins), ch, 3, 3, ctypes.byref(h)) == 0
+    xs = [torch.randn(B, H, W, -(-c // 4) * 4, generator=g) for c in cins]
+    for x, c in zip(xs, cins):
+        x[..., c:] = 0
+    xd = [x.to(dev) for x in xs]
+    ptrs = (ctypes.c_void_p * len(cins))(*[x.data_ptr() for x in xd])
+    strides = (ctypes.c_int * len(cins))(*[x.shape[-1] for x in xd])
+    outs = []
+    for knob in (0, 31):
+        lib.pivlfn_tune(12, 1)          # Winograd from one output pixel up (the network's dispatch starts it at 64 x 64)
+        lib.pivlfn_tune(14, knob)
+        y = torch.full((B, H, W, co), float("nan"), device=dev)
+        rc = lib.pivlfn_conv2d_nhwc_cat(h, len(cins), ptrs, strides, y.data_ptr(), co, B, H, W, 1, torch.cuda.current_stream(dev).cuda_stream)
+        lib.pivlfn_tune(14, 0)
+        lib.pivlfn_tune(12, 0)
+        assert rc == 0, lib.pivlfn_last_error()
+        outs.append(y.cpu())
+    lib.pivlfn_conv_destroy(h)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])

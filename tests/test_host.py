@@ -235,3 +235,20 @@ def test_bench_py_refuses_more_ranks_than_devices():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "device(s) visible" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_py_parent_reports_a_dead_rank_quickly():
+    """No GPU needed: with the gloo backend the parent starts two ranks; rank 1 exits 3 on request (rank 0 stops at its own "needs a GPU"
+    assertion here).  The parent must return non-zero within seconds, name a rank with its exit code and show that rank's stderr --
+    not sit in a wait for the other one."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, PIVLFN_BENCH_BACKEND="gloo", PIVLFN_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert time.monotonic() - t0 < 60
+    assert "exited with code" in r.stderr and "--- stderr tail of rank" in r.stderr, r.stderr[-1500:]

@@ -21,6 +21,7 @@ def load() -> ctypes.CDLL:
         lib = ctypes.CDLL(PATH)
         sigs = dict(_lib.SIGNATURES)
         sigs["pivlfn_tune"] = (ctypes.c_int, [ctypes.c_int, ctypes.c_int])
+        sigs["pivlfn_conv2d_nhwc_wino4"] = (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_void_p])
         for name, (res, args) in sigs.items():
             fn = getattr(lib, name)
             fn.restype = res

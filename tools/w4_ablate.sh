@@ -7,7 +7,7 @@ MASKS=${1:-"0 1 2 4 8 12 16 31"}
 OBJ=build/obj
 mkdir -p gpurun_out/w4abl
 for m in $MASKS; do
-  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -DW4_ABL_CT=$m -c piv_liteflownet-pytorch_amd/csrc/conv_wino4.hip -o gpurun_out/w4abl/w4_$m.o
+  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -DW4_ABL_CT=$m -c -Ipiv_liteflownet-pytorch_amd/csrc tools/kernels/conv_wino4.hip -o gpurun_out/w4abl/w4_$m.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/w4abl/lib_$m.so $(ls $OBJ/*.o | grep -v conv_wino4.o) gpurun_out/w4abl/w4_$m.o
 done
 python3 - "$MASKS" <<'PY'
