@@ -36,7 +36,10 @@ def pick_dispatches(rows):
     else:
         assert len(ids) % 6 == 0, f"{len(ids)} warp+correlation dispatches: not a whole number of forwards"
         pick = [d for k, d in enumerate(ids) if 6 - k % 6 == level][1:]          # the first forward is the warm-up
-    want = EXPECT[(level, batch)]
+    want = EXPECT.get((level, batch))
+    if want is None:
+        sys.exit(f"pmc_summary.py: no expected kernel is recorded for level {level} at batch {batch} (known: {sorted(EXPECT)}): add it to EXPECT "
+                 "after checking which kernel the launch policy picks for that shape")
     for d in pick:
         name = by_disp[d][0]["Kernel_Name"]
         assert want in name, f"dispatch {d} picked for level {level} batch {batch} is {name!r}, expected {want}"
