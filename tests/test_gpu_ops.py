@@ -211,13 +211,17 @@ def test_channels_last_kernels_vs_oracle_at_launch_sizes(shape, dev):
     print(f"{shape}: |kernel - f64| {e_got:.2e}  |NCHW kernel - f64| {e_other:.2e}  |oracle - f64| {e_orc:.2e}  |kernel - oracle| {rel(got, want):.2e}")
     assert e_got <= 2.0 * e_orc + 2e-6, (e_got, e_orc)
     assert e_other <= 2.0 * e_orc + 2e-6, (e_other, e_orc)
+    # an absolute ceiling as well (above 256 px the first two bounds are relative to the oracle's own position rounding, measured
+    # 3.0e-5 at 512 x 520), and the two kernels -- both in pixel units, the same fma contraction -- against each other
+    assert e_got < 6e-5 and e_other < 6e-5, (e_got, e_other)
+    assert rel(got, other) < 3e-6, rel(got, other)
     if max(H, W) <= 256:
         assert rel(got, want) < 2e-5, rel(got, want)
 
 
 def test_one_wrong_tap_fails_the_float64_yardstick():
-    """The yardstick above is sharp: the oracle with ONE bilinear tap of one pixel dropped is 1e-3 of max|out| from float64, a
-    thousand times the bound."""
+    """The yardstick above is sharp: the oracle with ONE bilinear tap of one pixel dropped is ~1e-3 of max|out| from float64, more than
+    a hundred times the bound (asserted: > 100 x)."""
     g = np.random.default_rng(5)
     f1 = g.standard_normal((1, 64, 48, 40)).astype(np.float32)
     f2 = g.standard_normal((1, 64, 48, 40)).astype(np.float32)
@@ -234,7 +238,7 @@ def test_one_wrong_tap_fails_the_float64_yardstick():
     f2w_bad[0, :, 24, 20] -= f2[0, :, y0, x0] * np.float32((1 - ax) * (1 - ay))       # the (0, 0) tap of pixel (24, 20) left out
     bad = orc.correlation_c(f1, f2w_bad, 2)
     bad = np.where(bad >= 0, bad, 0.1 * bad)
-    assert rel(bad, exact) > 1000 * (2.0 * e_orc + 2e-6) / 10 and rel(bad, exact) > 2.0 * e_orc + 2e-6
+    assert rel(bad, exact) > 100 * (2.0 * e_orc + 2e-6)
 
 
 def test_warp_corr_batch_beyond_2_gib(dev):
@@ -243,6 +247,9 @@ def test_warp_corr_batch_beyond_2_gib(dev):
     (round 4 returned PIVLFN_ERR_ARG from B = 37 up)."""
     lib = _lib.load()
     B, C, n, s = 40, 64, 1024, 2
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 30 * 2 ** 30:      # 2 x 10.7 GB of features + 2.35 GB of output + flow
+        pytest.skip(f"{free / 2 ** 30:.0f} GiB of device memory free: the test takes ~25 GB")
     st = torch.cuda.current_stream(dev).cuda_stream
     g = torch.Generator(device=dev).manual_seed(11)
     f1 = torch.randn(B, n, n, C, device=dev, generator=g)
