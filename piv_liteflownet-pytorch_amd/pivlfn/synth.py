@@ -254,15 +254,21 @@ class ParticleSequence:
         inten = 240.0 * torch.exp(-(self.z ** 2))
         for k in range(k0, k1):
             xs, ys = self._positions(k)
-            x = torch.from_numpy(xs).to(self.device, torch.float32)[:, None]
-            y = torch.from_numpy(ys).to(self.device, torch.float32)[:, None]
+            # (float32 by numpy: a torch CPU conversion wakes torch's thread pool, whose spinning workers then slow the next frame's
+            #  numpy advection down from 0.6 to 10 ms -- measured with tools/render_time.py)
+            x = torch.from_numpy(xs.astype(np.float32)).to(self.device)[:, None]
+            y = torch.from_numpy(ys.astype(np.float32)).to(self.device)[:, None]
             ix, iy = torch.floor(x).long() + ox, torch.floor(y).long() + oy
             val = inten[:, None] * torch.exp(-((ix - x) ** 2 + (iy - y) ** 2) / ((0.5 * self.d[:, None]) ** 2))
             ok = (ix >= 0) & (ix < self.W) & (iy >= 0) & (iy < self.H)
             # accumulate in 2^-16 fixed point: integer adds commute, so the frame does not depend on the order in which the
             # device's atomic adds land (float index_add_ on a GPU does, and a frame could differ by one grey level between
-            # two renderings -- ranks must agree on the halo frame they both render)
+            # two renderings -- ranks must agree on the halo frame they both render).  Footprint pixels outside the image add
+            # an exact 0 to a clamped index instead of being filtered out: boolean indexing is a device-to-host round trip per
+            # frame (15 ms per 1024 x 1024 frame in round 1 -- longer than the network's forward), and the sums are the same integers.
+            add = torch.round(val * 65536.0).to(torch.int64) * ok
+            idx = iy.clamp(0, self.H - 1) * self.W + ix.clamp(0, self.W - 1)
             img = torch.zeros(self.H * self.W, dtype=torch.int64, device=self.device)
-            img.index_add_(0, (iy * self.W + ix)[ok], torch.round(val[ok] * 65536.0).to(torch.int64))
+            img.index_add_(0, idx.reshape(-1), add.reshape(-1))
             out[k - k0] = (img.view(self.H, self.W).to(torch.float64) / 65536.0).clamp_(0, 255).to(torch.uint8)
         return out

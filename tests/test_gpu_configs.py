@@ -202,6 +202,33 @@ def test_bench_py_two_rank_rehearsal(dev):
     assert abs(j["value"] - 2 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 0.01                  # value = all ranks' pairs / max time
 
 
+def test_config3_one_ranks_share_at_length(dev):
+    """A whole per-rank share of BASELINE configs[3] on one GPU: 1 251 frames of 1024 x 1024 (1 250 pairs, 157 chunks of 8) through
+    run_sequence with a sink that drops the flows -- the pinned ring, the producer thread and the sink thread over a long run: every
+    pair reaches the sink exactly once and in order per chunk, host memory stays flat, and the loop runs at the forward's rate (the
+    frames of the next chunk are rendered while the current one is estimated)."""
+    import resource
+    from pivlfn.sequence import run_sequence
+    S, n_frames, chunk = 1024, 1251, 8
+    net = pivlfn.piv_liteflownet(synth.generate_weights("piv", 0)).to(dev).eval()
+    seq = synth.ParticleSequence(S, S, seed=7, device=dev)
+    got = []
+    rss = []
+
+    def sink(gi, flow):
+        got.append(gi)
+        assert flow.shape == (S, S, 2)
+        if gi % 200 == 0:
+            rss.append(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)
+    st = run_sequence(net, seq.frames, n_frames, chunk, dev, sink=sink)
+    assert got == list(range(n_frames - 1)) and st["flows_emitted"] == n_frames - 1
+    assert rss[-1] - rss[1] < 200 * 1024, rss          # KiB: no growth with the number of chunks once the ring is allocated
+    rate = (n_frames - 1) / st["seconds"]
+    est = (n_frames - 1) / st["seconds_estimation"]
+    print(f"1250 pairs: {rate:.1f} pairs/s whole loop, {est:.1f} pairs/s in the estimation")
+    assert rate > 0.8 * est, (rate, est)
+
+
 def test_bench_py_starts_its_own_ranks(dev):
     """The plain command `python bench.py --gpus 2` with no outer launcher and no RANK / WORLD_SIZE in the environment: the parent
     starts two fresh ranks itself (gloo here: one GPU) and relays rank 0's single JSON line; asking for more devices than are

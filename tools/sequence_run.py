@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--chunk", type=int, default=8, help="pairs per forward / per gather on every rank")
     ap.add_argument("--write", default=None, help="directory for rank 0's .flo files")
+    ap.add_argument("--null-sink", action="store_true", help="hand every flow to a sink that drops it (the loop without the disk)")
+    ap.add_argument("--no-gather", action="store_true", help="no all-gather: every rank hands its own shard to its own sink / writer")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"])
     ap.add_argument("--model", default="piv")
     ap.add_argument("--seed", type=int, default=99)
@@ -50,7 +52,15 @@ def main():
     seq = synth.ParticleSequence(a.size, a.size, seed=a.seed, device=dev)
     if dist is not None:
         dist.barrier()
-    st = run_sequence(net, seq.frames, a.frames, a.chunk, dev, write_dir=a.write, rank=rank, world=world)
+    import resource
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    seen = [0]
+
+    def null_sink(gi, flow):
+        seen[0] += 1
+    st = run_sequence(net, seq.frames, a.frames, a.chunk, dev, write_dir=a.write, sink=null_sink if a.null_sink else None, rank=rank, world=world,
+                      gather=not a.no_gather)
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     if dist is not None:
         dist.barrier()
     if rank == 0:
@@ -58,6 +68,7 @@ def main():
         print(json.dumps({"workload": f"{a.frames} frames {S}x{S} ({st['pairs_total']} pairs), {world} rank(s), chunk {a.chunk}, {a.precision}",
                           "pairs_per_s_estimation_only_rank0": round(st["pairs_this_rank"] / st["seconds_estimation"], 2) if st["seconds_estimation"] else None,
                           "pairs_per_s_whole_loop": round(st["pairs_total"] / st["seconds"], 2), "seconds": round(st["seconds"], 2),
+                          "flows_handed_to_the_sink": st["flows_emitted"], "max_rss_mb_before_after": [round(rss0 / 1024), round(rss1 / 1024)],
                           "flo_files_written": st["flows_emitted"] if a.write else 0,
                           "flo_gb_written": round(st["flows_emitted"] * (12 + S * S * 8) / 1e9, 2) if a.write else 0.0}), flush=True)
     if dist is not None:
