@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-arithmetic", action="store_true", help="skip the side-by-side timing of the three fp32 conv arithmetics")
     ap.add_argument("--lean", action="store_true", help="only the timed forwards (no level-1 / batch-8 / conv roofline extras): for profiler runs")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed warm runs of the CPU baseline (median reported)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_wino_mfma32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"],
                     help="how the large convolutions multiply: fp32 (the library's default and the headline: the fp32 matrix instruction, "
                          "3x3 stride-1 layers by Winograd F(2x2,3x3) in fp32), fp32_direct (the same instruction, direct convolution "
                          "everywhere), fp32_split (fp32 operands as three fp16 pieces = all 24 bits, six partial products on the fp16 "
@@ -131,10 +131,18 @@ def counter_file_value(name, key):
 
 DTYPE = {       # the arithmetic type the path computes in (short), and what that means (dtype_note)
     "fp32": ("f32",
-             "fp32 data, operands (all 24 bits), products and accumulators: v_mfma_f32_32x32x2_f32 in every convolution (exact fp32 fma chains); "
-             "the 3x3 stride-1 layers (95 % of the multiplies) by Winograd F(2x2,3x3) in fp32 -- the minimal-filtering algorithm cuDNN / MIOpen "
-             "use for fp32 3x3 layers: 2.25x fewer multiplies, input / output transforms are fp32 additions, filter transform in float64 rounded "
-             "once to fp32; error against a float64 convolution at or below the direct kernel's (tests/test_gpu_wino.py)"),
+             "fp32 data, operands (all 24 significand bits of every multiplicand), products and accumulators.  The 3x3 stride-1 layers (95 % of "
+             "the multiplies) by Winograd F(2x2,3x3) -- the minimal-filtering algorithm cuDNN / MIOpen use for fp32 3x3 layers: 2.25x fewer "
+             "multiplies, input / output transforms are fp32 additions, filter transform in float64 rounded once to fp32.  WHAT MULTIPLIES WHAT: in "
+             "the Winograd layers with whole 64-channel output groups, >= 64 input channels and >= 256x256 outputs per image (csrc/conv_wino_b3.hip; "
+             "two thirds of the forward's multiplies) each fp32 operand U or V is split EXACTLY into three bf16 values h + m + l (8 + 8 + 8 "
+             "significand bits, fp32's exponent range: no narrower input domain, no scaling) and U*V is accumulated in fp32 on "
+             "v_mfma_f32_32x32x16_bf16 from the six piece products hh, hm, mh, hl, mm, lh, each exact; dropped: ml + lm + ll <= 2^-23 |U V| (2^-26 "
+             "typically), below the rounding of an fp32 fma -- measured against float64 the layer error is at or below that of both "
+             "fp32-instruction kernels, and 6, 8 and 9 piece products agree to three digits (tests/test_gpu_wino_b3.py); bit-identical across "
+             "batch.  Every other convolution (the remaining Winograd layers, all direct ones) multiplies fp32 x fp32 on v_mfma_f32_32x32x2_f32 "
+             "(exact fp32 fma chains)"),
+    "fp32_wino_mfma32": ("f32", "the default of rounds 3-5: as fp32 with every Winograd layer on v_mfma_f32_32x32x2_f32 (csrc/conv_wino.hip)"),
     "fp32_direct": ("f32", "v_mfma_f32_32x32x2_f32, direct convolution in every layer"),
     "fp32_split": ("f32 (products from fp16x6 split operands on the f16 MFMA, f32 accumulate)",
                    "fp32 data, accumulators and results; each operand of the large convolutions enters the fp16 matrix cores as three fp16 "
@@ -144,7 +152,7 @@ DTYPE = {       # the arithmetic type the path computes in (short), and what tha
                     "(22-23 significand bits), 3 partial products per product, relative product error <= 2^-21"),
     "fp16": ("f16 multiplicands, f32 accumulate", "BASELINE config #5: operands rounded to fp16"),
 }
-FP32_WIDE = ("fp32", "fp32_direct", "fp32_split")      # arithmetics that keep all 24 operand bits: only these may carry the fp32 metric name
+FP32_WIDE = ("fp32", "fp32_wino_mfma32", "fp32_direct", "fp32_split")      # arithmetics that keep all 24 operand bits: only these may carry the fp32 metric name
 
 
 def arithmetic_modes(net, i1, i2, steps, dev):
@@ -152,7 +160,7 @@ def arithmetic_modes(net, i1, i2, steps, dev):
     difference from the direct fp32-instruction result."""
     keep = net.precision
     res, ref = {}, None
-    for mode in ("fp32_direct", "fp32", "fp32_split", "fp32_split3"):
+    for mode in ("fp32_direct", "fp32_wino_mfma32", "fp32", "fp32_split", "fp32_split3"):
         net.precision = mode
         for _ in range(3):
             flow = net(i1, i2)
@@ -168,8 +176,10 @@ def arithmetic_modes(net, i1, i2, steps, dev):
                      "max_abs_px_vs_fp32_direct": round(float((flow - ref).abs().max()), 7),
                      "operand_bits": 24 if mode in FP32_WIDE else 23}
     net.precision = keep
-    res["what"] = ("fp32_direct = v_mfma_f32_32x32x2_f32, direct convolution everywhere; fp32 (the headline) = the same instruction with the 3x3 "
-                   "stride-1 layers by Winograd F(2x2,3x3) in fp32; fp32_split / fp32_split3 = the residual-free convs with >= 256x256 / >= 64x64 "
+    res["what"] = ("fp32_direct = v_mfma_f32_32x32x2_f32, direct convolution everywhere; fp32_wino_mfma32 (the headline of rounds 3-5) = the same "
+                   "instruction with the 3x3 stride-1 layers by Winograd F(2x2,3x3); fp32 (the headline) = that with the large Winograd layers' "
+                   "operands split exactly into three bf16 pieces on v_mfma_f32_32x32x16_bf16 (six exact piece products per product, all 24 bits: "
+                   "dtype_note); fp32_split / fp32_split3 = the residual-free convs with >= 256x256 / >= 64x64 "
                    "outputs per image on v_mfma_f32_32x32x16_f16 with fp32 operands split into 3 / 2 fp16 pieces (6 / 3 partial products, fp32 "
                    "accumulate); fp32_split3 keeps 22-23 operand bits and is not an fp32-wide arithmetic")
     return res
@@ -198,6 +208,8 @@ def conv_roofline(dev, precision, launches=40):
         if terms:
             _lib.check(lib.pivlfn_conv2d_nhwc_split(h, x.data_ptr(), ci, y.data_ptr(), co, 1, n, n, 1, 1, 1, 1, terms, st), "conv")
         elif precision == "fp32":
+            _lib.check(lib.pivlfn_conv2d_nhwc_wino_b3(h, x.data_ptr(), ci, y.data_ptr(), co, 1, n, n, 1, 6, st), "conv")
+        elif precision == "fp32_wino_mfma32":
             _lib.check(lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), ci, y.data_ptr(), co, 1, n, n, 1, st), "conv")
         else:
             _lib.check(lib.pivlfn_conv2d_nhwc(h, x.data_ptr(), ci, y.data_ptr(), co, None, 0, 1, n, n, 1, 1, 1, 1, st), "conv")
@@ -223,6 +235,21 @@ def conv_roofline(dev, precision, launches=40):
                 "note": "fp16 matrix work actually executed (terms x 2 x pixels x Cin x Cout x 9) / median duration; the chip sustains ~1600 TFLOP/s of this "
                         "instruction on random operands (1.70 GHz under power, tools/micro/mfma_f16_power.hip, profiles/r02_mfma_f16_power.log)"}
     if precision == "fp32":
+        ex = 6 * flop / 2.25      # F(2x2,3x3): 16 multiplies per 2x2 output tile and channel pair instead of 36, six bf16 piece products each
+        cnt = counter_file_value("r06_pmc_b3.json", "pivlfn::conv_wino_b3_kernel<6>") or {}
+        return {"bound": "mfma", "achieved": round(ex / t / 1e12, 1), "peak": 2516.0, "unit": "TFLOP/s", "frac": round(ex / t / 2.516e15, 4), "traffic": None,
+                "kernel": "conv_wino_b3_kernel<6>, 128->128 3x3 at 1024x1024 B=1 (Winograd F(2x2,3x3), operands split exactly into 3 bf16 pieces, 6 piece "
+                          "products per product on v_mfma_f32_32x32x16_bf16)",
+                "fp32_winograd_equivalent_tflops": round(flop / 2.25 / t / 1e12, 1), "direct_equivalent_tflops": round(flop / t / 1e12, 1), **spread,
+                "sustainable_on_random_operands_tflops": 1800.0,
+                "counters": {k: cnt.get(k) for k in ("mfma_busy_frac", "clock_GHz", "valu_per_mfma", "hbm_read_MB", "hbm_write_MB", "median_us")} if cnt else None,
+                "note": "achieved = bf16 matrix work actually executed (6 x 2 x 16/4 x pixels x Cin x Cout) / median duration against the dense bf16 "
+                        "peak; a bare loop of this instruction on random data sustains ~1.8 PFLOP/s at 1.74 GHz (power), the kernel's own K loop with its "
+                        "transform / split vector work and weight-fragment loads 1.05-1.2 PFLOP/s (tools/micro/wino_bf16_loop.hip, "
+                        "profiles/r06_wino_bf16_loop.log); counters (profiles/r06_pmc_b3.json): the matrix pipe is busy ~38 % of the launch at 2.05 GHz, "
+                        "6.9 vector instructions per MFMA -- one wave per SIMD (256 accumulator registers), so every wait is exposed: the patch loads "
+                        "that go to HBM cost a quarter of a K step (the same loads from an L2-resident window: profiles/r06_b3_patch_window_ablation.log)"}
+    if precision == "fp32_wino_mfma32":
         ex = flop / 2.25          # F(2x2,3x3): 16 multiplies per 2x2 output tile and channel pair instead of 36
         return {"bound": "mfma", "achieved": round(ex / t / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ex / t / 157.3e12, 4), "traffic": None,
                 "kernel": "conv_wino_kernel<1, 2>, 128->128 3x3 at 1024x1024 B=1 (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
@@ -501,9 +528,14 @@ def main():
                     # region of 64 channels: 3.06 x the tile's own 8.0 KB x 8 of f2) through its own load path, served by the Infinity
                     # Cache at 33.5 GB/s per CU (MI355X_MICROARCH.md, Indexed rows: a lower bound of the rate), behind a
                     # flow -> taps round trip (~1 us) that cannot overlap it; plus the output's way out.  DESIGN.md 4.1b.
-                    "floor_us": round(200e3 / 33.5e9 * 1e6 + 1.0, 2) if (B == 1 and S == 1024 and L == 3 and args.model == "piv") else None,
-                    "floor_note": "batch 1 puts ONE tile on each CU: 200 KB per CU gathered at the Infinity-Cache gather rate of one CU "
-                                  "(33.5 GB/s) = 6.0 us, + ~1 us flow -> taps dependency; frac is quoted against 8 TB/s all the same",
+                    # (renamed in round 6: this was called floor_us, but the guide lists 33.5 GB/s under per-CU rates that are LOWER bounds --
+                    #  it is an estimate of one share of the launch, not a floor; the same launch on L2-resident inputs takes 7.8-7.9 us
+                    #  standalone: profiles/r06_wc_descriptor_ab.log)
+                    "model_us": round(200e3 / 33.5e9 * 1e6 + 1.0, 2) if (B == 1 and S == 1024 and L == 3 and args.model == "piv") else None,
+                    "model_note": "an ESTIMATE of the gather-arrival share, not a lower bound: batch 1 puts ONE tile on each CU, 200 KB per CU "
+                                  "at the Infinity-Cache gather rate the guide lists for one CU (33.5 GB/s, itself a lower bound of that rate) = 6.0 us, "
+                                  "+ ~1 us flow -> taps dependency; measured: 7.8-7.9 us back to back on cache-resident inputs, 9.7-10.3 us inside "
+                                  "the forward; frac is quoted against 8 TB/s all the same",
                     "timer": "HIP start/stop events attached to the dispatch (hipExtLaunchKernelGGL) in every timed step, on the "
                              "stream the kernel runs on; event_record_pair_us = plain hipEventRecord pair around the same launch "
                              "(adds the marker packets' own cost); rocprofv3_kernel_trace_avg_us: a plain --kernel-trace pass "
