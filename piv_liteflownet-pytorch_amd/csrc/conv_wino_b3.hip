@@ -44,6 +44,9 @@
 #include "common.h"
 #include "wino_common.h"
 
+#ifndef B3_GINNER
+#define B3_GINNER 0      // 1: a workgroup takes the channel groups of a spatial tile one after the other (measured 1-2 % SLOWER: profiles/r06_b3_group_order_ab.log)
+#endif
 namespace pivlfn {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -93,18 +96,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4 *smem4 = reinterpret_cast<f32x4 *>(smem);
 
-    // ---- this workgroup's tiles.  Persistent workgroups (one per CU): every XCD owns a contiguous band of tile ids (xcd_remap's bands)
-    // and its workgroups take the band's tiles round-robin, so the workgroups of an XCD work on neighbouring tiles at any time and the
-    // channel groups of one spatial tile (consecutive ids) run side by side: the patch comes from HBM once and from that L2 afterwards.
+    // ---- this workgroup's tiles.  Persistent workgroups (one per CU): every XCD owns a contiguous band of tiles (xcd_remap's bands)
+    // and its workgroups take the band's tiles round-robin, so the workgroups of an XCD work on neighbouring tiles at any time.
+    // Two orders.  The flat one (production): tile id = spatial tile x NG + channel group, so the channel groups of a spatial tile run
+    // on neighbouring workgroups at the same time and share the patch's lines in the XCD's L2.  B3_GINNER=1 (with at least one spatial tile
+    // per workgroup) lets ONE workgroup take the channel groups of a spatial tile one after the other, so that the second group's patch
+    // loads are L2 hits: a patch load that goes to HBM costs a quarter of a K step (B3_ABL_PATCHNEAR) -- but measured 1-2 % slower on
+    // every layer (profiles/r06_b3_group_order_ab.log): the neighbour's concurrent request already turns the second miss into a hit.
     const int NG = p.cout_pad >> 6;             // 64-channel groups
     const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
-    const int total = p.B * tiles_y * tiles_x * NG;
+    const int sp_total = p.B * tiles_y * tiles_x;
+    const bool ginner = B3_GINNER && NG > 1 && sp_total >= (int)gridDim.x;
+    const int units = ginner ? sp_total : sp_total * NG;      // what the bands and the round-robin count: spatial tiles or tiles
     const int xcd = blockIdx.x & 7;
     const int tstride = ((int)gridDim.x - xcd + 7) >> 3;      // workgroups on this XCD
-    const int tq = total >> 3, tr = total & 7;
-    const int tend = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + tq + (xcd < tr ? 1 : 0);
-    int ctile = tend - tq - (xcd < tr ? 1 : 0) + (int)(blockIdx.x >> 3);       // the tile being multiplied
-    if (ctile >= tend) return;
+    const int tq = units >> 3, tr = units & 7;
+    const int uend = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + tq + (xcd < tr ? 1 : 0);
+    const int ufirst = uend - tq - (xcd < tr ? 1 : 0) + (int)(blockIdx.x >> 3);       // this workgroup's first unit
+    if (ufirst >= uend) return;
+    const int ntiles = ((uend - ufirst + tstride - 1) / tstride) * (ginner ? NG : 1);       // tiles this workgroup multiplies
+    const int tile0 = ginner ? ufirst * NG : ufirst;           // id of the first one (channel group fastest)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,15 +161,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wpk_b), 0, (unsigned)min(wbytes, (size_t)0xffffffffu), 0x00020000);
     const int wstep = NG * 4 * BWAVE * 16;                      // bytes per K step
     const int wlane = lane * 16;
-    int woff = ((ctile % NG) * 4 + wave) * BWAVE * 16;          // this wave's fragments of the current step
+    int woff = ((tile0 % NG) * 4 + wave) * BWAVE * 16;          // this wave's fragments of the current step
 
     // ---- the load stream: (tile, step) whose patch is fetched next, two steps ahead of the matrix work and across tile boundaries
     const size_t img_px = (size_t)p.H * p.W;
-    int ltile = ctile, lseg = 0, lc0 = 0, ly0 = 0, lx0 = 0, lrow0 = 0;
+    int lleft = ntiles - 1, lseg = 0, lc0 = 0, ly0 = 0, lx0 = 0, lrow0 = 0;      // lleft: tiles the load stream has in front of it
     // tile coordinates without divisions in the loop: (channel group, tile column, tile row, image) of the load stream, advanced by the
     // decomposed stride with carries; the tile being multiplied is the one the load stream left at its last B3_LNEXT
-    int lng = ctile % NG, ltx = (ctile / NG) % tiles_x, lty = (ctile / NG / tiles_x) % tiles_y, lb = ctile / NG / tiles_x / tiles_y;
-    const int dng = tstride % NG, dtx = (tstride / NG) % tiles_x, dty = (tstride / NG / tiles_x) % tiles_y, db = tstride / NG / tiles_x / tiles_y;
+    int lng = tile0 % NG, ltx = (tile0 / NG) % tiles_x, lty = (tile0 / NG / tiles_x) % tiles_y, lb = tile0 / NG / tiles_x / tiles_y;
+    // the stride between two tiles of this workgroup, decomposed: flat order = tstride tile ids; ginner = the next channel group of the
+    // same spatial tile, then tstride spatial tiles on
+    const int dsp = ginner ? tstride : tstride / NG;
+    const int dng = ginner ? 0 : tstride % NG, dtx = dsp % tiles_x, dty = (dsp / tiles_x) % tiles_y, db = dsp / tiles_x / tiles_y;
     int cng = lng, cx0 = ltx * 16, cy0 = lty * 16, cb = lb;
     __amdgpu_buffer_rsrc_t rsv[3];
     // byte offset of the thread's record in slot 1..5 (+ s x lrstep) and in slot 0, inside the load tile's current source (the descriptor
@@ -234,15 +248,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_LNEXT()                                                                                \
     do {                                                                                          \
         cng = lng; cx0 = lx0; cy0 = ly0; cb = lb;                                                 \
-        ltile += tstride;                                                                         \
-        if (ltile < tend) {                                                                       \
-            lng += dng;                                                                           \
-            if (lng >= NG) { lng -= NG; ++ltx; }                                                  \
-            ltx += dtx;                                                                           \
-            if (ltx >= tiles_x) { ltx -= tiles_x; ++lty; }                                        \
-            lty += dty;                                                                           \
-            if (lty >= tiles_y) { lty -= tiles_y; ++lb; }                                         \
-            lb += db;                                                                             \
+        if (lleft > 0) {                                                                          \
+            --lleft;                                                                              \
+            if (ginner && lng + 1 < NG) {                                                         \
+                ++lng;              /* the next channel group of the same spatial tile: same patch, same descriptors */ \
+            } else {                                                                              \
+                lng = ginner ? 0 : lng + dng;                                                     \
+                if (lng >= NG) { lng -= NG; ++ltx; }                                              \
+                ltx += dtx;                                                                       \
+                if (ltx >= tiles_x) { ltx -= tiles_x; ++lty; }                                    \
+                lty += dty;                                                                       \
+                if (lty >= tiles_y) { lty -= tiles_y; ++lb; }                                     \
+                lb += db;                                                                         \
+            }                                                                                     \
             B3_LTILE();                                                                           \
         } else {                                                                                  \
             lseg = 0; lc0 = 0;                                                                    \
@@ -450,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     B3_VPLANE(0, 0);
     __syncthreads();
 #endif
-    for (;;) {
+    for (int ti = 0; ti < ntiles; ++ti) {
 #if !B3_XTILE
         // tile start: bo2 holds the tile's first image, bo1 its second
         B3_LANE_ADDRS();
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         __syncthreads();            // every wave has read the first image: its buffer is free for the tile's third step
 #endif
         BSTAMP(0);
-        const int ntile = ctile + tstride;
+        const bool has_next = ti + 1 < ntiles;
         for (int c = 0; c + 1 < p.nchunk; ++c) {
             if (c == p.nchunk - 2) {
                 B3_LNEXT();
@@ -472,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         }
         // the step after a tile's last one is the next tile's first: the load stream stands on that tile (past the last tile: the same
         // fragments again, loaded and never used)
-        const int wfirst = ntile < tend ? (lng * 4 + wave) * BWAVE * 16 : woff;
+        const int wfirst = has_next ? (lng * 4 + wave) * BWAVE * 16 : woff;
 #if B3_XTILE
         B3_STEP(wfirst);
 #else
@@ -580,8 +598,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #ifdef PIVLFN_STAMPS
         if (stamp_) sd_[6] += 1;
 #endif
-        ctile = ntile;
-        if (ctile >= tend) break;
     }
 #ifdef PIVLFN_STAMPS
     if (stamp_ && lane == 0) {
