@@ -134,7 +134,7 @@ DTYPE = {       # the arithmetic type the path computes in (short), and what tha
              "fp32 data, operands (all 24 significand bits of every multiplicand), products and accumulators.  The 3x3 stride-1 layers (95 % of "
              "the multiplies) by Winograd F(2x2,3x3) -- the minimal-filtering algorithm cuDNN / MIOpen use for fp32 3x3 layers: 2.25x fewer "
              "multiplies, input / output transforms are fp32 additions, filter transform in float64 rounded once to fp32.  WHAT MULTIPLIES WHAT: in "
-             "the Winograd layers with whole 64-channel output groups, >= 64 input channels and >= 256x256 outputs per image (csrc/conv_wino_b3.hip; "
+             "the Winograd layers with whole 64-channel output groups, >= 48 input channels and >= 256x256 outputs per image (csrc/conv_wino_b3.hip; "
              "two thirds of the forward's multiplies) each fp32 operand U or V is split EXACTLY into three bf16 values h + m + l (8 + 8 + 8 "
              "significand bits, fp32's exponent range: no narrower input domain, no scaling) and U*V is accumulated in fp32 on "
              "v_mfma_f32_32x32x16_bf16 from the six piece products hh, hm, mh, hl, mm, lh, each exact; dropped: ml + lm + ll <= 2^-23 |U V| (2^-26 "
@@ -301,18 +301,18 @@ def l3_throughput_regime(dev, batch=8, launches=40):
     t_disp = us.value * 1e-6
     t = t_b2b                        # the conservative figure (as in rounds 1-3): one event pair around all launches
     alg = l3_algorithmic_bytes(batch, 1024, 1024, 3, C, s)
-    traffic, traffic_src = counter_traffic("r05_pmc_l3b8_warp_corr.json") if batch == 8 else (None, "no counter pass for this batch")
+    traffic, traffic_src = counter_traffic("r06_pmc_l3b8_warp_corr.json") if batch == 8 else (None, "no counter pass for this batch")
     return {"bound": "hbm", "achieved": round(alg / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / t / 8e12, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(t * 1e6, 2), "avg_dispatch_event_us": round(t_disp * 1e6, 2),
-            "rocprofv3_kernel_trace_avg_us": counter_file_value("r05_pmc_l3b8_warp_corr.json", "rocprofv3_kernel_trace_avg_us") if batch == 8 else None,
+            "rocprofv3_kernel_trace_avg_us": counter_file_value("r06_pmc_l3b8_warp_corr.json", "rocprofv3_kernel_trace_avg_us") if batch == 8 else None,
             "algorithmic_bytes_per_launch": alg, "launches_timed": launches,
             "kernel": "warp_corr_v6_kernel<true, 2> (persistent workgroups, sliding window over runs of 8 tiles)",
             "timer": "avg_launch_us: one event pair around all back-to-back launches / launches (contains the ~3 us between two dependent "
                      "kernels of a stream; the figure of rounds 1-3); avg_dispatch_event_us: start/stop events attached to every dispatch "
                      "(pivlfn_warp_corr_nhwc_timed) -- with launches queued back to back a dispatch's start stamp is taken while its "
                      "predecessor still runs, so this reads LONGER than the kernel; rocprofv3_kernel_trace_avg_us: the average "
-                     "of a plain rocprofv3 --kernel-trace pass over the same launches, as stored in profiles/r05_pmc_l3b8_warp_corr.json "
+                     "of a plain rocprofv3 --kernel-trace pass over the same launches, as stored in profiles/r06_pmc_l3b8_warp_corr.json "
                      "(taken on the profile box, not in this run)",
             "workload": f"level-3 warp+correlation of batch {batch} x 1024x1024 (C=64, stride 2, 2048 tiles), back-to-back launches"}
 
@@ -516,13 +516,13 @@ def main():
             t_k = k_ms / k_n * 1e-3                       # start/stop events attached to the dispatch itself
             t_pair = k_empty_ms / k_n * 1e-3              # plain hipEventRecord pair around the same launch (incl. marker cost)
             ach = alg / t_k / 1e9
-            traffic, traffic_src = (counter_traffic("r05_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
+            traffic, traffic_src = (counter_traffic("r06_pmc_l3_warp_corr.json") if (B == 1 and S == 1024 and L == 3 and args.model == "piv")
                                     else (None, "no counter pass for this workload"))
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": f"{'warp_corr_v7_kernel (one tile per CU)' if (C % 64 == 0 and B * (S // (2 ** (L - 1)) // stride // 8) ** 2 <= torch.cuda.get_device_properties(dev).multi_processor_count) else 'warp_corr_v6_kernel (persistent)'} (level {L}: C={C}, stride {stride})",
                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(t_k * 1e6, 2), "launches_timed": k_n,
                     "event_record_pair_us": round(t_pair * 1e6, 2),
-                    "rocprofv3_kernel_trace_avg_us": counter_file_value("r05_pmc_l3_warp_corr.json", "rocprofv3_kernel_trace_avg_us")
+                    "rocprofv3_kernel_trace_avg_us": counter_file_value("r06_pmc_l3_warp_corr.json", "rocprofv3_kernel_trace_avg_us")
                     if (B == 1 and S == 1024 and L == 3 and args.model == "piv") else None,
                     # what one tile per CU can reach: a CU gathers 200 KB (the 14 x 14 stride-2 positions x 4 taps touch a 28 x 28
                     # region of 64 channels: 3.06 x the tile's own 8.0 KB x 8 of f2) through its own load path, served by the Infinity
@@ -539,7 +539,7 @@ def main():
                     "timer": "HIP start/stop events attached to the dispatch (hipExtLaunchKernelGGL) in every timed step, on the "
                              "stream the kernel runs on; event_record_pair_us = plain hipEventRecord pair around the same launch "
                              "(adds the marker packets' own cost); rocprofv3_kernel_trace_avg_us: a plain --kernel-trace pass "
-                             "over the same launch of the same forward, stored in profiles/r05_pmc_l3_warp_corr.json"}
+                             "over the same launch of the same forward, stored in profiles/r06_pmc_l3_warp_corr.json"}
         fp32_grade = args.precision in FP32_WIDE
         out = {
             "metric": (("PIV" if args.model == "piv" else "LiteFlowNet (Hui weights layout)") +
@@ -569,12 +569,12 @@ def main():
         if l1 is not None and l1[2]:
             alg1 = l3_algorithmic_bytes(B, S, S, 1, 64, 2)
             t1 = l1[0] / l1[2] * 1e-3
-            tr1, src1 = counter_traffic("r05_pmc_l1_warp_corr.json") if B == 1 else (None, "no counter pass for this workload")
+            tr1, src1 = counter_traffic("r06_pmc_l1_warp_corr.json") if B == 1 else (None, "no counter pass for this workload")
             out["roofline_level1"] = {"bound": "hbm", "achieved": round(alg1 / t1 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                       "frac": round(alg1 / t1 / 8e12, 4), "traffic": tr1, "traffic_source": src1,
                                       "kernel": "warp_corr_v6_kernel<true, 2> (level 1: C=64, stride 2; 395 MB per launch, beyond the Infinity Cache; runs of 16 tiles)",
                                       "algorithmic_bytes_per_launch": alg1, "avg_launch_us": round(t1 * 1e6, 2), "launches_timed": l1[2],
-                                      "rocprofv3_kernel_trace_avg_us": counter_file_value("r05_pmc_l1_warp_corr.json", "rocprofv3_kernel_trace_avg_us") if B == 1 else None}
+                                      "rocprofv3_kernel_trace_avg_us": counter_file_value("r06_pmc_l1_warp_corr.json", "rocprofv3_kernel_trace_avg_us") if B == 1 else None}
         if world == 1 and args.model == "piv" and S == 1024 and not args.lean:
             out["roofline_batch8"] = l3_throughput_regime(dev)
         if world == 1 and args.precision != "fp16" and args.model == "piv" and S == 1024 and not args.lean:

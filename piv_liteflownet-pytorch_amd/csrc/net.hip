@@ -18,6 +18,10 @@ static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 // Split-K scratch (conv_mfma.hip): a layer is split only when one image has <= 128 workgroups of 128 px x 32 channels, i.e. at
 // most 128*128*32 partial sums per share and image, and into at most 8 shares.
 static const size_t KSPLIT_FLOATS = (size_t)8 * 128 * 128 * 32;
+// The reduction of the shares is a kernel of its own (16 launches of 6.7 us at 1024^2).  Round 6 let the share that arrives last at a
+// tile do it (arrival counter, agent-scope release / acquire fences; same order, same bits): the forward got 0.42 ms SLOWER
+// (profiles/r06_item5_net_ab.log) -- a release at agent scope writes back the XCD's whole L2 (eight L2s that are not coherent with
+// each other), ~500 workgroups x 16 layers of it while the side stream keeps 1.4 GB of dirty lines going.  Not adopted.
 
 void pack_conv_h(const float *w, int cout, int cin, int taps, const int *creal, const int *cload, const int *coff, int nseg,
                  std::vector<unsigned short> &pk, int *nchunk_out);      // conv_f16.hip
@@ -705,15 +709,16 @@ static int conv(const ConvW &cw, std::initializer_list<ConvSeg> segs, float *out
         int i = 0, cl = 0;
         for (auto &sg : segs) { q.seg[i++] = sg; cl += sg.cload; }
         q.nseg = i;
-        // Default fp32 mode: layers with whole 64-channel output groups and at least 64 staged input channels run the same Winograd
+        // Default fp32 mode: layers with whole 64-channel output groups and at least 48 staged input channels run the same Winograd
         // algorithm with every operand split exactly into three bf16 pieces on the 16-bit matrix cores (conv_wino_b3.hip; all 24
-        // significand bits, error against float64 at or below the fp32 instruction's: tests/test_gpu_wino_b3.py) -- 1.03-1.25 x the
-        // speed of the fp32-instruction kernel on those layers at 256^2 ... 1024^2; narrower inputs (conv_M.0: 49 channels) and the 32-
-        // and 96-channel layers stay on conv_wino.hip.  Per layer shape, never per batch.  PIVLFN_PRECISION_F32_WINO_MFMA32 keeps
+        // significand bits, error against float64 at or below the fp32 instruction's: tests/test_gpu_wino_b3.py) -- 1.08-1.3 x the
+        // speed of the fp32-instruction kernel on those layers at 256^2 ... 1024^2 (conv_M.0's 49 channels, four K steps: 1.08-1.16);
+        // 32-channel inputs (two steps per tile: the tile's fixed cost decides, 1.0 x) and the 32- and 96-channel outputs stay on
+        // conv_wino.hip.  Per layer shape, never per batch.  PIVLFN_PRECISION_F32_WINO_MFMA32 keeps
         // every layer on the fp32 instruction.
         // From 256 x 256 outputs per image: its persistent workgroups (one per CU, 16 x 16 pixels x 64 channels per tile) need at least a
         // tile per CU; the 128 x 128 layers of level 4 took 23-64 us on it against 12-25 us on conv_wino.hip.
-        if (!t_no_b3 && cw.wpk_wb && conv_wino_b3_supports(cw.cout_pad) && cl >= 64 && (long)Ho * Wo >= 256 * 256 && !(PIV_KNOB(1) & 2097152) &&
+        if (!t_no_b3 && cw.wpk_wb && conv_wino_b3_supports(cw.cout_pad) && cl >= 48 && (long)Ho * Wo >= 256 * 256 && !(PIV_KNOB(1) & 2097152) &&
             (long)16 * W * out_stride * 4 < (1L << 31)) {
             q.wpk_b = cw.wpk_wb; q.bias = cw.bias; q.out = out; q.out_stride = out_stride; q.cout_store = cout_store;
             q.cout_pad = cw.cout_pad;

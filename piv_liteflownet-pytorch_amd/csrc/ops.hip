@@ -165,6 +165,57 @@ __global__ __launch_bounds__(256) void touch_kernel(const f32x4 *__restrict__ p,
     if (a[0] + a[1] + a[2] + a[3] == 1.2345678e38f) sink[0] = a[0];       // never true in practice: keeps the loads alive
 }
 
+// The same layer with a 2 x 2 output block per thread (Q > 1: the 49-channel correlation at levels 2 and 1, 235 MB of output at 1024²):
+// the outputs (2m+1 .. 2m+2) x (2n+1 .. 2n+2) all read the input pixels (m .. m+1) x (n .. n+1), so a thread loads four input quads
+// instead of sixteen and its sixteen weight quads once.  Every output sums its taps in dwconvT_kernel's order (input row m+1 before m,
+// column n+1 before n, out-of-range taps skipped): the bits are the same.  Blocks m = -1 .. H-1, n = -1 .. W-1; blockIdx =
+// (segment of 256 (block column, quad) items, block row + 1, image).
+template <int Q>
+__global__ __launch_bounds__(256) void dwconvT_b2_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                         float *__restrict__ out, int H, int W, int sin, int sout)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int nb = j / Q, q = j - nb * Q;
+    if (nb > W) return;
+    const int n = nb - 1, m = (int)blockIdx.y - 1, b = blockIdx.z;
+    const int Wo = 2 * W;
+    f32x4 v[2][2];            // [input row m+1, m][input column n+1, n]
+    bool ok[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int iy = m + 1 - a, ix = n + 1 - c;
+            ok[a][c] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            v[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok[a][c]) v[a][c] = *reinterpret_cast<const f32x4 *>(in + ((size_t)(b * H + iy) * W + ix) * sin + 4 * q);
+        }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int oy = 2 * m + 1 + dy;
+        if (oy < 0 || oy >= 2 * H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int ox = 2 * n + 1 + dx;
+            if (ox < 0 || ox >= Wo) continue;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (!ok[a][c]) continue;
+                    const int ky = dy + 2 * a, kx = dx + 2 * c;      // oy = 2 iy - 1 + ky with iy = m + 1 - a
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + ((ky * 4 + kx) * Q + q) * 4);
+                    acc[0] = fmaf(v[a][c][0], wv[0], acc[0]);
+                    acc[1] = fmaf(v[a][c][1], wv[1], acc[1]);
+                    acc[2] = fmaf(v[a][c][2], wv[2], acc[2]);
+                    acc[3] = fmaf(v[a][c][3], wv[3], acc[3]);
+                }
+            *reinterpret_cast<f32x4 *>(out + ((size_t)(b * 2 * H + oy) * Wo + ox) * sout + 4 * q) = acc;
+        }
+    }
+}
+
 int launch_touch(const float *p, size_t floats, float *sink, hipStream_t st)
 {
     const size_t n = floats / 4;
@@ -184,7 +235,13 @@ int launch_dwconvT(const float *in, const float *w, float *out, int B, int H, in
     const dim3 grid((unsigned)cdiv(2 * W * Q, 256), (unsigned)(2 * H), (unsigned)B);
     switch (Q) {
         case 1: hipLaunchKernelGGL(dwconvT_kernel<1>, grid, dim3(256), 0, st, in, w, out, H, W, stride_in, stride_out); break;       // flow (u, v, 0, 0)
-        case 14: hipLaunchKernelGGL(dwconvT_kernel<14>, grid, dim3(256), 0, st, in, w, out, H, W, stride_in, stride_out); break;     // 49 + 7 correlation lanes
+        case 14:                                                                                                                     // 49 + 7 correlation lanes
+            if (PIV_KNOB(1) & 8388608)      // tools: the one-output-per-thread kernel (A/B)
+                hipLaunchKernelGGL(dwconvT_kernel<14>, grid, dim3(256), 0, st, in, w, out, H, W, stride_in, stride_out);
+            else
+                hipLaunchKernelGGL(dwconvT_b2_kernel<14>, dim3((unsigned)cdiv((W + 1) * Q, 256), (unsigned)(H + 1), (unsigned)B), dim3(256), 0, st, in, w, out, H, W,
+                                   stride_in, stride_out);
+            break;
         default: PIV_REQUIRE(false, "dwconvT: %d channel quads not instantiated (1 = flow, 14 = correlation)", Q);
     }
     PIV_CHECK_HIP(hipGetLastError());

@@ -93,7 +93,7 @@ class LiteFlowNet(torch.nn.Module):
     def precision(self) -> str:
         """How the large convolutions multiply (everything else -- correlation, warps, heads, small levels -- is fp32 throughout):
         'fp32'        (default) fp32 operands (all 24 bits), fp32 products and accumulation.  The 3x3 stride-1 layers by Winograd F(2x2, 3x3):
-                      those with whole 64-channel output groups and >= 64 input channels with every operand split exactly into three
+                      those with whole 64-channel output groups and >= 48 input channels with every operand split exactly into three
                       bf16 pieces on v_mfma_f32_32x32x16_bf16 (csrc/conv_wino_b3.hip: six exact piece products per product, what is
                       dropped is <= 2^-23 of it; fp32's input domain), the others on the fp32 matrix-core instruction
                       v_mfma_f32_32x32x2_f32 (csrc/conv_wino.hip); every other layer by direct convolution on that instruction;

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Everything profiles/rNN_* is made from, in one go on the GPU box (from the repo root):  bash tools/profile_round.sh
+# PARTS=short: only the kernel table, the warp+correlation counters and the split-operand Winograd counters (what bench.py reads)
 # (rocprofv3 runs with the program itself after `--`; counters in their own --pmc passes, never combined with other trace domains)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -12,13 +13,17 @@ python3 tools/stats_md.py $R/prof_fp32 3 > $R/kernel_stats_fp32.md
 python3 tools/level_timeline.py $R/prof_fp32 > $R/timeline_fp32.txt
 echo "stats done"
 # 2. warp+correlation counter passes (level 3, level 1, batch-8 level 3)
-bash tools/pmc_l3.sh > $R/pmc_l3.log 2>&1
+PMC_ROUND=$RN bash tools/pmc_l3.sh > $R/pmc_l3.log 2>&1
 cp gpurun_out/pmc_l3/${RN}_pmc_*.json $R/
 echo "pmc_l3 done"
+[ "$PARTS" = "short" ] && { bash tools/pmc_b3.sh > $R/pmc_b3.log 2>&1; cp gpurun_out/pmc_b3/${RN}_pmc_b3.json $R/; echo "short: done"; exit 0; }
 # 3. config #3 (32 x 512^2) counter passes on the level-3 warp+correlation
 bash tools/pmc_config3.sh > $R/${RN}_pmc_config3.json 2> $R/pmc_config3.err || echo "pmc_config3 failed"
 echo "config3 done"
-# 4. Winograd kernel counters: busy / waits, then instruction mix
+# 4. Winograd kernel counters: the split-operand kernel beside the fp32 one (traffic, matrix-pipe busy, clock); busy / waits and
+#    instruction mix of the fp32 one
+bash tools/pmc_b3.sh > $R/pmc_b3.log 2>&1 || echo "pmc_b3 failed"
+cp gpurun_out/pmc_b3/${RN}_pmc_b3.json $R/ || true
 bash tools/pmc_wino.sh > $R/${RN}_pmc_wino_busy.json 2> $R/pmc_wino_busy.err
 PMC="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM" bash tools/pmc_wino.sh > $R/${RN}_pmc_wino_insts.json 2> $R/pmc_wino_insts.err
 echo "pmc_wino done"
