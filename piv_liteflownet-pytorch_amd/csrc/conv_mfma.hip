@@ -627,7 +627,12 @@ constexpr int C3_PW = 38, C3_PITCH = 116, C3_PH = 14;         // patch of an 8 x
 // FUSE: the level-1 1 x 1 layers on top (Conv1Fuse): the accumulator layout of the 32 x 32 x 2 instruction is already its B-operand
 // layout -- lane (pixel, hh) holds channels 8 g + 4 hh + e in register 4 g + e, and k-slot hh of the MFMA (g, e) wants exactly that
 // channel -- so the activated accumulators feed the next MFMAs without a transpose: 16 MFMAs per 32 output channels.
-template <bool FUSE>
+// Round 6, where the fused kernel's 450 us go (tools/c3k7_ablate.sh, profiles/r06_c3k7_ablation.log): stores alone 248 us (1.34 GB at
+// 5.4 TB/s), matrix work + loads alone 362 us, loads alone 95 us -- the phases overlap only partly.  Two ways of overlapping them more
+// were built and are SLOWER on the same box: the next patch written to a second LDS buffer before the tile's stores are issued (so that
+// no wait has stores in front of it; 470 vs 448 us), and the 1 x 1 blocks software-pipelined over two accumulator sets (MFMAs of block
+// k + 1 between the activation / stores of block k; 522 vs 462 us; tools/kernels/conv_c3k7_pipelined_blocks.hip.txt).
+template <bool FUSE, int ABL = 0>
 __global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const ConvParams p, const Conv1Fuse f)
 {
     __shared__ __attribute__((aligned(16))) float patch[C3_PH * C3_PITCH + 4];
@@ -679,6 +684,9 @@ __global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const Conv
         }                                                                                         \
     } while (0)
 
+    // ABL != 0: instances of the tools build for timing runs (tools/c3k7_ablate.sh): 1 no stores of the fused 1 x 1 layers, 2 no conv1
+    // stores, 4 no MFMAs of the fused layers, 8 no conv1 MFMAs, 16 no patch loads after the first
+    constexpr int abl = ABL;
     C3_LOAD(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();          // the previous tile's operand reads are done
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const Conv
             }
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) C3_LOAD(tile + gridDim.x);
+        if (tile + (int)gridDim.x < ntiles && !(abl & 16)) C3_LOAD(tile + gridDim.x);
         f32x16 acc[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -706,7 +714,9 @@ __global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const Conv
 #pragma unroll
                 for (int m = 0; m < 2; ++m) a[m] = patch[abase[m] + ky * C3_PITCH + 2 * j];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[ky][j], a[m], acc[m], 0, 0, 0);
+                for (int m = 0; m < 2; ++m)
+                    if (!(abl & 8)) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[ky][j], a[m], acc[m], 0, 0, 0);
+                    else acc[m][j & 15] += a[m];
             }
         int t_ = tile;
         const int tx = t_ % tiles_x;
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const Conv
                 if (p.lrelu) {
                     v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
                 }
-                if (ok && 8 * g + 4 * hh < p.cout_store) *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * hh) = v;
+                if (ok && 8 * g + 4 * hh < p.cout_store && !(abl & 2)) *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * hh) = v;
                 if (FUSE) { acc[m][4 * g + 0] = v[0]; acc[m][4 * g + 1] = v[1]; acc[m][4 * g + 2] = v[2]; acc[m][4 * g + 3] = v[3]; }
             }
         }
@@ -746,7 +756,9 @@ __global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const Conv
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) a2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e], acc[m][4 * g + e], a2[m], 0, 0, 0);
+                        for (int m = 0; m < 2; ++m)
+                            if (!(abl & 4)) a2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e], acc[m][4 * g + e], a2[m], 0, 0, 0);
+                            else a2[m][4 * g + e] += wv[e] * acc[m][4 * g + e];
                 }
                 const bool ext = blk < 2;
                 const int cb = ext ? 32 * blk : 32 * (blk - 2), cs = ext ? 64 : 128;
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(256, FUSE ? 2 : 3) void conv_c3k7_kernel(const Conv
                         f32x4 v = {a2[m][4 * g + 0], a2[m][4 * g + 1], a2[m][4 * g + 2], a2[m][4 * g + 3]};
                         v += *reinterpret_cast<const f32x4 *>(bsrc + 8 * g);
                         v[0] = lrelu01(v[0]); v[1] = lrelu01(v[1]); v[2] = lrelu01(v[2]); v[3] = lrelu01(v[3]);
-                        *reinterpret_cast<f32x4 *>(orow + 8 * g) = v;
+                        if (!(abl & 1) || v[0] == 1.2345e38f) *reinterpret_cast<f32x4 *>(orow + 8 * g) = v;
                     }
                 }
             }
@@ -794,7 +806,16 @@ int launch_conv1_fused(const ConvParams &p, const Conv1Fuse &f, hipStream_t st)
     if ((long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) < 512) return -1;             // per image: never a function of the batch
     const long tiles = (long)cdiv(p.Wo, 32) * cdiv(p.Ho, 8) * p.B;
     const int cus = device_cus();
+#ifdef PIVLFN_TOOLS
+#define C3_ABL(M) case M: hipLaunchKernelGGL((conv_c3k7_kernel<true, M>), dim3((unsigned)std::min<long>(tiles, 2L * cus)), dim3(256), 0, st, p, f); break;
+    switch (PIV_KNOB(7)) {
+        C3_ABL(1) C3_ABL(2) C3_ABL(3) C3_ABL(4) C3_ABL(5) C3_ABL(12) C3_ABL(15) C3_ABL(28) C3_ABL(31)
+        default: hipLaunchKernelGGL((conv_c3k7_kernel<true>), dim3((unsigned)std::min<long>(tiles, 2L * cus)), dim3(256), 0, st, p, f);
+    }
+#undef C3_ABL
+#else
     hipLaunchKernelGGL((conv_c3k7_kernel<true>), dim3((unsigned)std::min<long>(tiles, 2L * cus)), dim3(256), 0, st, p, f);
+#endif
     PIV_CHECK_HIP(hipGetLastError());
     return PIVLFN_OK;
 }
