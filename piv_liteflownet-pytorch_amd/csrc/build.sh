@@ -23,7 +23,9 @@ build_one() {   # $1 = object dir, $2 = output .so, $3 = extra flags, $4 = extra
     objs+=("$OBJ/$f.o")
     if [ ! -f "$OBJ/$f.o" ] || [ "$f.hip" -nt "$OBJ/$f.o" ]; then
       # warp_corr: the SLP vectoriser packs the consumers' fma chains into v_pk_fma_f32 behind 2-4 v_mov each (measured in the ISA)
-      local PERFILE=""; [ "$f" = "warp_corr" ] && PERFILE="-fno-slp-vectorize"
+      # conv_wino_b3: v_pk_add_f32 / v_pk_fma_f32 cost 11 cycles of the wave's issue time against 2 x 4-5 for the scalar pair
+      # (tools/micro/mfma_shadow.hip), and that kernel's one wave per SIMD is issue-bound: 1 % (profiles/r06_b3_lds_ring_ab.log)
+      local PERFILE=""; { [ "$f" = "warp_corr" ] || [ "$f" = "conv_wino_b3" ]; } && PERFILE="-fno-slp-vectorize"
       hipcc $FLAGS $PERFILE -c "$f.hip" -o "$OBJ/$f.o" &
       pids+=($!)
     fi

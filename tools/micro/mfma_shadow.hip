@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
     // every instruction of the loop body is a volatile asm statement: the order below is the order in the binary
 #define MFMA(m) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[(m) & 3]) : "v"(A), "v"(B[(m) & 3]))
 #define FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(i) % 24]) : "v"(c0), "v"(c1))
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; MODE < 3 && it < iters; ++it) {
         if (MODE == 0) {
 #pragma unroll
             for (int m = 0; m < 16; ++m) MFMA(m);
@@ -45,8 +45,41 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
             }
         }
     }
-#undef MFMA
 #undef FMA
+    // MODE 3: the split's own instruction mix, 7 per MFMA and independent of each other: 2 v_cvt_pk_bf16_f32, 2 shifts, 2 ands, 1 v_pk_add_f32
+    // MODE 4: seven v_cvt_pk_bf16_f32; MODE 5: seven v_pk_add_f32; MODE 6: seven v_lshlrev_b32
+    if (MODE >= 3) {
+        float2 pk[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
+        unsigned w[8];
+        for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(unsigned, v[8 + i]);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                MFMA(m);
+                // every instruction updates a register of its own in place (results stay live: dead outputs would all be given one
+                // register and the compiler would put an s_nop between two asm statements that write it)
+                if (MODE == 3) {
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(w[0]) : "v"(v[17]));
+                    asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(w[1]));
+                    asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(w[2]));
+                    asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(pk[m & 3]) : "v"(pk[(m + 2) & 3]));
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(w[3]) : "v"(v[19]));
+                    asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(w[6]));
+                    asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(w[7]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+                        if (MODE == 4) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(w[q]) : "v"(v[17]));
+                        if (MODE == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[q & 3]) : "v"(pk[(q + 2) & 3]));
+                        if (MODE == 6) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(w[q]));
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < 8; ++i) v[i] += __builtin_bit_cast(float, w[i]);
+        for (int i = 0; i < 4; ++i) v[8 + i] += pk[i].x + pk[i].y;
+    }
+#undef MFMA
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
     for (int a = 0; a < 4; ++a)
@@ -75,9 +108,10 @@ static void run(const char *what, float *out, float *in, unsigned long long *cyc
     double mean = 0;
     for (auto c : h) mean += (double)c;
     mean /= cus;
-    // s_memtime / readcyclecounter ticks at 100 MHz: convert through the wall time
+    // the kernel's own counter (s_memtime: shader clocks on this part -- 2.07e9 per second of a conv_wino_b3 launch) beside the wall time
     const double us_per_iter = ms * 1e3 / iters;
-    printf("%-78s %7.3f us / iteration = %6.0f cycles at 2.0 GHz  (16 MFMAs alone: 512)   %.3f ms\n", what, us_per_iter, us_per_iter * 2000.0, ms);
+    printf("%-78s %7.3f us / iteration, %6.0f counter ticks / iteration (%.2f GHz if they are clocks; 16 MFMAs alone: 512)\n", what, us_per_iter,
+           mean / iters, mean / iters / us_per_iter / 1e3);
 }
 
 int main()
@@ -98,5 +132,9 @@ int main()
     run<2, 96>("16 x (MFMA, 6 fmas) interleaved, one result per group feeds a later MFMA's B operand", out, in, cyc, cus);
     run<0, 192>("16 MFMAs, then 192 fmas (grouped)", out, in, cyc, cus);
     run<1, 192>("16 x (MFMA, 12 fmas) interleaved", out, in, cyc, cus);
+    run<3, 0>("16 x (MFMA, the split's mix: 2 cvt_pk_bf16, 2 shifts, 2 ands, 1 pk_add_f32)", out, in, cyc, cus);
+    run<4, 0>("16 x (MFMA, 7 v_cvt_pk_bf16_f32)", out, in, cyc, cus);
+    run<5, 0>("16 x (MFMA, 7 v_pk_add_f32)", out, in, cyc, cus);
+    run<6, 0>("16 x (MFMA, 7 v_lshlrev_b32)", out, in, cyc, cus);
     return 0;
 }

@@ -8,7 +8,10 @@ OUT=$PWD/gpurun_out/pmc_b3
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 LAYERS=${LAYERS:-128x128}
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
+# PMC_GROUPS: other counter groups, separated by ';' (e.g. "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"); PMC_JSON: output name
+IFS=';' read -ra GROUPS_ <<< "${PMC_GROUPS:-FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE;SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAVE_CYCLES}"
+export PMC_JSON=${PMC_JSON:-r06_pmc_b3.json}
+for grp in "${GROUPS_[@]}"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/$tag" -- python3 tools/bench_b3.py --layers $LAYERS --rounds 1 --n 3 > "$OUT/$tag.log" 2>&1 || { echo "pass $tag failed"; tail -3 "$OUT/$tag.log"; }
 done
@@ -47,6 +50,6 @@ for k, c in agg.items():
     if "SQ_INSTS_VALU" in e and "SQ_INSTS_MFMA" in e:
         e["valu_per_mfma"] = round((e["SQ_INSTS_VALU"] - e["SQ_INSTS_MFMA"]) / e["SQ_INSTS_MFMA"], 3)
     res[k] = e
-json.dump(res, open(os.path.join(out, "r06_pmc_b3.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, os.environ.get("PMC_JSON", "r06_pmc_b3.json")), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
