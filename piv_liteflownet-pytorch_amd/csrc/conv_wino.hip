@@ -459,8 +459,8 @@ int launch_conv_w(const ConvParamsW &p_in, hipStream_t st)
     const long sp1 = (long)p.B * cdiv(p.H, 8) * cdiv(p.W, 16), sp2 = (long)p.B * cdiv(p.H, 16) * cdiv(p.W, 16);
     int mb = sp2 * nb >= 512 ? 2 : 1;
 #ifdef PIVLFN_TOOLS
-    // Round 5's persistent kernel with specialised waves (conv_wino_ws.hip): same values bit for bit, 4-8 % slower than this kernel
-    // on every layer -- compiled into the tools library only, for A/B runs (knob 14 = 31).
+    // Round 5's persistent kernel with specialised waves (conv_wino_ws.hip): same values bit for bit (tests/test_gpu_wino.py), 4-8 % slower than this
+    // kernel on the 128-channel layers and up to 24 % on 64 -> 32 / 32 -> 32 (profiles/r05_bench_wino_ws.log) -- compiled into the tools library only, for A/B runs (knob 14 = 31).
     if (PIV_KNOB(14) == 31 && conv_wino_ws_items(p) > 0) return launch_conv_w_ws(p, st);
 #endif
 #ifdef PIVLFN_TOOLS

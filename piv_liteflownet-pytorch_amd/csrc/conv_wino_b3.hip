@@ -56,9 +56,13 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 // LDS image of one K step's patch (18 x 18 pixels x 16 channels fp32): pixel records of 4 channel quads + 1 quad of padding (odd
 // pitch), rows and columns de-interleaved (even then odd) as in conv_wino.hip, row pitch 104 quads = 8 mod 16: the 16 lanes of every
 // ds_read_b128 group (tile rows {0,3} x columns 0-3 and rows {1,2} x columns 4-7, or the complement) land on 16 distinct 16-byte slots.
-// Staged through registers (buffer_load_dwordx4 -> ds_write_b128, four lanes per 64-byte pixel record).  LDS-DMA was built and measured
-// (git history): a DMA lands ~3000 cycles after its issue here, and the in-order vmcnt makes the first wait for a LATER weight-fragment
-// load wait for it as well -- one phase (~1200 cycles) of slack.
+// Staged through registers (buffer_load_dwordx4 -> ds_write_b128, four lanes per 64-byte pixel record).  LDS-DMA was built twice:
+// first for the patch alone (a DMA lands ~3000 cycles after its issue, and the in-order vmcnt makes the first wait for a LATER
+// weight-fragment load wait for it as well), then for everything -- weight fragments through a 96 KB LDS ring three phases ahead, the
+// patch a whole step ahead, every wait written by hand (tools/kernels/conv_wino_b3_lds_ring.patch.txt): bit-identical and at parity
+// with this file (profiles/r06_b3_lds_ring_ab.log).  The K loop is not waiting for latency: one wave per SIMD issues ~920 instructions
+// per step at 4-10 cycles each, and the workgroups pull 8 TB/s out of the L2s.  Built with -fno-slp-vectorize
+// (build.sh): v_pk_add_f32 / v_pk_fma_f32 take 11 cycles of the wave's issue time, the scalar pair 8 (tools/micro/mfma_shadow.hip).
 constexpr int BPIXQ = 5;        // 16-byte quads per staged pixel: 16 channels + 4 floats of padding
 constexpr int BROWQ = 104;      // quads per patch row: 18 x 5 = 90, padded to 8 mod 16
 constexpr int BPH = 18;         // patch rows = columns: 8 tiles x 2 + 2

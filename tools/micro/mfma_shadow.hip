@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
     }
 #undef FMA
     // MODE 3: the split's own instruction mix, 7 per MFMA and independent of each other: 2 v_cvt_pk_bf16_f32, 2 shifts, 2 ands, 1 v_pk_add_f32
-    // MODE 4: seven v_cvt_pk_bf16_f32; MODE 5: seven v_pk_add_f32; MODE 6: seven v_lshlrev_b32
+    // MODE 4: seven v_cvt_pk_bf16_f32; MODE 5: seven v_pk_add_f32; MODE 6: seven v_lshlrev_b32; 7: v_dot2_f32_bf16; 8: v_sub_f32; 9: v_perm_b32
     if (MODE >= 3) {
         float2 pk[4] = {{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}};
         unsigned w[8];
@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
                         if (MODE == 4) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(w[q]) : "v"(v[17]));
                         if (MODE == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[q & 3]) : "v"(pk[(q + 2) & 3]));
                         if (MODE == 6) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(w[q]));
+                        if (MODE == 7) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(v[q]) : "v"(w[7]), "v"(0x0000bf80u));
+                        if (MODE == 8) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[q]) : "v"(v[17]));
+                        if (MODE == 9) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(w[q]) : "v"(w[7]), "v"(0x07060302u));
                     }
                 }
             }
@@ -136,5 +139,8 @@ int main()
     run<4, 0>("16 x (MFMA, 7 v_cvt_pk_bf16_f32)", out, in, cyc, cus);
     run<5, 0>("16 x (MFMA, 7 v_pk_add_f32)", out, in, cyc, cus);
     run<6, 0>("16 x (MFMA, 7 v_lshlrev_b32)", out, in, cyc, cus);
+    run<7, 0>("16 x (MFMA, 7 v_dot2_f32_bf16)", out, in, cyc, cus);
+    run<8, 0>("16 x (MFMA, 7 v_sub_f32)", out, in, cyc, cus);
+    run<9, 0>("16 x (MFMA, 7 v_perm_b32)", out, in, cyc, cus);
     return 0;
 }
