@@ -246,9 +246,11 @@ def conv_roofline(dev, precision, launches=40):
                 "note": "achieved = bf16 matrix work actually executed (6 x 2 x 16/4 x pixels x Cin x Cout) / median duration against the dense bf16 "
                         "peak; a bare loop of this instruction on random data sustains ~1.8 PFLOP/s at 1.74 GHz (power), the kernel's own K loop with its "
                         "transform / split vector work and weight-fragment loads 1.05-1.2 PFLOP/s (tools/micro/wino_bf16_loop.hip, "
-                        "profiles/r06_wino_bf16_loop.log); counters (profiles/r06_pmc_b3.json): the matrix pipe is busy ~38 % of the launch at 2.05 GHz, "
-                        "6.9 vector instructions per MFMA -- one wave per SIMD (256 accumulator registers), so every wait is exposed: the patch loads "
-                        "that go to HBM cost a quarter of a K step (the same loads from an L2-resident window: profiles/r06_b3_patch_window_ablation.log)"}
+                        "profiles/r06_wino_bf16_loop.log); counters (profiles/r06_pmc_b3.json, quoted in `counters`): the matrix pipe is busy ~38 % of the launch "
+                        "at ~2.0 GHz with 7-8 vector instructions per MFMA -- one wave per SIMD (256 accumulator registers) can issue the step's ~920 "
+                        "instructions no faster (a plain vector instruction takes 4 cycles in an MFMA's shadow, an MFMA ~10 of issue: "
+                        "tools/micro/mfma_shadow.hip), and the workgroups pull 8 TB/s out of the L2s, 80 % of it weight fragments; a variant with every "
+                        "memory request a whole step ahead (LDS ring + LDS-DMA) runs at parity (profiles/r06_b3_lds_ring_ab.log): DESIGN.md 4.2f"}
     if precision == "fp32_wino_mfma32":
         ex = flop / 2.25          # F(2x2,3x3): 16 multiplies per 2x2 output tile and channel pair instead of 36
         return {"bound": "mfma", "achieved": round(ex / t / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ex / t / 157.3e12, 4), "traffic": None,
