@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     // ---- the load stream: (tile, step) whose patch is fetched next, two steps ahead of the matrix work and across tile boundaries
     const size_t img_px = (size_t)p.H * p.W;
     int lleft = ntiles - 1, lseg = 0, lc0 = 0, ly0 = 0, lx0 = 0, lrow0 = 0;      // lleft: tiles the load stream has in front of it
+    int lscl = p.seg[0].cload;      // staged channels of the load stream's source -- kept in a scalar register: as p.seg[lseg].cload it was an
+                                    // s_load per step whose lgkmcnt(0) also waited for every LDS read in flight
     // tile coordinates without divisions in the loop: (channel group, tile column, tile row, image) of the load stream, advanced by the
     // decomposed stride with carries; the tile being multiplied is the one the load stream left at its last B3_LNEXT
     int lng = tile0 % NG, ltx = (tile0 / NG) % tiles_x, lty = (tile0 / NG / tiles_x) % tiles_y, lb = tile0 / NG / tiles_x / tiles_y;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
             rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[ss].ptr) + ((long)lb_ * (long)img_px + (long)lrow0 * p.W) * p.seg[ss].stride, 0, \
                                                        (unsigned)min(left * 4, (size_t)0x7fffffff), 0x00020000); \
         }                                                                                         \
-        lseg = 0; lc0 = 0;                                                                        \
+        lseg = 0; lc0 = 0; lscl = p.seg[0].cload;                                                 \
         B3_PVO(0);                                                                                \
     } while (0)
 // patch of the load stream's step -> PR, then advance the stream inside its tile (the loads and this rare branch sit at the top of a
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     do {                                                                                          \
         const bool sw_ = lc0 >= (SCL) && lseg + 1 < p.nseg;                                       \
         lseg += sw_ ? 1 : 0;                                                                      \
+        lscl = p.seg[lseg].cload;                                                                 \
         lc0 = sw_ ? 0 : lc0;                                                                      \
         B3_PVO(lseg);                                                                             \
     } while (0)
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     do {                                                                                          \
         if (lc0 >= (SCL) && lseg + 1 < p.nseg) {                                                  \
             ++lseg;                                                                               \
+            lscl = p.seg[lseg].cload;                                                             \
             lc0 = 0;                                                                              \
             B3_PVO(lseg);                                                                         \
         }                                                                                         \
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #endif
 #define B3_LOADP(PR)                                                                              \
     do {                                                                                          \
-        const int scl_ = p.seg[lseg].cload;                                                       \
+        const int scl_ = lscl;                                                                    \
         const __amdgpu_buffer_rsrc_t rs_ = lseg == 0 ? rsv[0] : (lseg == 1 ? rsv[1] : rsv[2]);    \
         int tq_ = tid;                                                                            \
         asm volatile("" : "+v"(tq_));       /* (tid & 3) * 4 kept as a loop invariant was the one register the allocator still spilled */ \
