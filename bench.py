@@ -301,19 +301,31 @@ def l3_throughput_regime(dev, batch=8, launches=40):
     _lib.check(lib.pivlfn_warp_corr_nhwc_timed(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out.data_ptr(), batch, C, n, n, s, 1,
                                                launches, ctypes.byref(us), st), "wc timed")
     t_disp = us.value * 1e-6
+    # ... and one dispatch at a time on an idle stream (host synchronisation in between): the start stamp is then taken when the kernel
+    # starts, so stop - start is the kernel alone -- the quantity rocprofv3's kernel trace reports
+    iso = []
+    for _ in range(launches):
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.pivlfn_warp_corr_nhwc_timed(f1.data_ptr(), f2.data_ptr(), fl.data_ptr(), 1.25, out.data_ptr(), batch, C, n, n, s, 1,
+                                                   1, ctypes.byref(us), st), "wc timed")
+        iso.append(us.value * 1e-6)
+    torch.cuda.synchronize(dev)
+    t_iso = sum(iso) / len(iso)
     t = t_b2b                        # the conservative figure (as in rounds 1-3): one event pair around all launches
     alg = l3_algorithmic_bytes(batch, 1024, 1024, 3, C, s)
     traffic, traffic_src = counter_traffic("r06_pmc_l3b8_warp_corr.json") if batch == 8 else (None, "no counter pass for this batch")
     return {"bound": "hbm", "achieved": round(alg / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / t / 8e12, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(t * 1e6, 2), "avg_dispatch_event_us": round(t_disp * 1e6, 2),
+            "avg_isolated_dispatch_us": round(t_iso * 1e6, 2), "frac_isolated_dispatch": round(alg / t_iso / 8e12, 4),
             "rocprofv3_kernel_trace_avg_us": counter_file_value("r06_pmc_l3b8_warp_corr.json", "rocprofv3_kernel_trace_avg_us") if batch == 8 else None,
             "algorithmic_bytes_per_launch": alg, "launches_timed": launches,
             "kernel": "warp_corr_v6_kernel<true, 2> (persistent workgroups, sliding window over runs of 8 tiles)",
             "timer": "avg_launch_us: one event pair around all back-to-back launches / launches (contains the ~3 us between two dependent "
                      "kernels of a stream; the figure of rounds 1-3); avg_dispatch_event_us: start/stop events attached to every dispatch "
                      "(pivlfn_warp_corr_nhwc_timed) -- with launches queued back to back a dispatch's start stamp is taken while its "
-                     "predecessor still runs, so this reads LONGER than the kernel; rocprofv3_kernel_trace_avg_us: the average "
+                     "predecessor still runs, so this reads LONGER than the kernel; avg_isolated_dispatch_us: the same events, one dispatch at a time "
+                     "on an idle stream -- the kernel alone, the quantity rocprofv3 reports; rocprofv3_kernel_trace_avg_us: the average "
                      "of a plain rocprofv3 --kernel-trace pass over the same launches, as stored in profiles/r06_pmc_l3b8_warp_corr.json "
                      "(taken on the profile box, not in this run)",
             "workload": f"level-3 warp+correlation of batch {batch} x 1024x1024 (C=64, stride 2, 2048 tiles), back-to-back launches"}
@@ -418,7 +430,7 @@ def main():
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        tmo = datetime.timedelta(seconds=float(os.environ.get("PIVLFN_BENCH_INIT_TIMEOUT_S", "120")))      # a missing rank is reported, not waited for
+        tmo = datetime.timedelta(seconds=float(os.environ.get("PIVLFN_BENCH_INIT_TIMEOUT_S", "600")))      # ranks of a fresh box page the image in at different speeds; a DEAD rank is reported by the parent within seconds
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)  # nccl == RCCL on ROCm
         else:

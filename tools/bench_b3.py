@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--wino-only", action="store_true", help="time the fp32-instruction Winograd kernel of every library instead (any channel counts)")
     a = ap.parse_args()
     paths = [_lib.LIB_PATH] + [p for p in a.libs.split(",") if p]
     libs = [load(p) for p in paths]
@@ -58,6 +59,12 @@ def main():
                 if i == 0:
                     ys["wino"] = torch.empty(a.batch, n, n, co, device=dev)
                     fns["wino"] = lambda lib=lib, h=h: lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, ys["wino"].data_ptr(), co, a.batch, n, n, 1, st)
+                if a.wino_only:
+                    if i:
+                        k = f"wino[{i}]"
+                        ys[k] = torch.empty(a.batch, n, n, co, device=dev)
+                        fns[k] = lambda lib=lib, h=h, k=k: lib.pivlfn_conv2d_nhwc_wino(h, x.data_ptr(), xs, ys[k].data_ptr(), co, a.batch, n, n, 1, st)
+                    continue
                 k = f"b3[{i}]"
                 ys[k] = torch.empty(a.batch, n, n, co, device=dev)
                 fns[k] = lambda lib=lib, h=h, k=k: lib.pivlfn_conv2d_nhwc_wino_b3(h, x.data_ptr(), xs, ys[k].data_ptr(), co, a.batch, n, n, 1, a.terms, st)
@@ -79,7 +86,7 @@ def main():
             out = f"L{L} {n}x{n} B={a.batch} {ci:3d}->{co:3d}:"
             for k, v in times.items():
                 d = (ys[k] - ref).abs().max().item() / ref.abs().max().item()
-                eq = "" if k in ("wino", "b3[0]") else f" bits==b3[0]: {bool(torch.equal(ys[k], ys['b3[0]']))}"
+                eq = "" if k in ("wino", "b3[0]") else (f" bits==wino: {bool(torch.equal(ys[k], ys['wino']))}" if a.wino_only else f" bits==b3[0]: {bool(torch.equal(ys[k], ys['b3[0]']))}")
                 out += f"   {k} min {min(v):7.1f} med {sorted(v)[len(v) // 2]:7.1f} us (x{min(times['wino']) / min(v):4.2f}; diff {d:.1e}{eq})"
             print(out, flush=True)
             for lib, h in zip(libs, hs):
