@@ -247,7 +247,7 @@ def conv_roofline(dev, precision, launches=40):
                         "peak; a bare loop of this instruction on random data sustains ~1.8 PFLOP/s at 1.74 GHz (power), the kernel's own K loop with its "
                         "transform / split vector work and weight-fragment loads 1.05-1.2 PFLOP/s (tools/micro/wino_bf16_loop.hip, "
                         "profiles/r06_wino_bf16_loop.log); counters (profiles/r06_pmc_b3.json, quoted in `counters`): the matrix pipe is busy ~38 % of the launch "
-                        "at ~2.0 GHz with 7-8 vector instructions per MFMA -- one wave per SIMD (256 accumulator registers) can issue the step's ~920 "
+                        "at ~2.0 GHz with 7-8 vector instructions per MFMA -- one wave per SIMD (256 accumulator registers) can issue the step's ~770 "
                         "instructions no faster (a plain vector instruction takes 4 cycles in an MFMA's shadow, an MFMA ~10 of issue: "
                         "tools/micro/mfma_shadow.hip), and the workgroups pull 8 TB/s out of the L2s, 80 % of it weight fragments; a variant with every "
                         "memory request a whole step ahead (LDS ring + LDS-DMA) runs at parity (profiles/r06_b3_lds_ring_ab.log): DESIGN.md 4.2f"}

@@ -60,7 +60,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 // first for the patch alone (a DMA lands ~3000 cycles after its issue, and the in-order vmcnt makes the first wait for a LATER
 // weight-fragment load wait for it as well), then for everything -- weight fragments through a 96 KB LDS ring three phases ahead, the
 // patch a whole step ahead, every wait written by hand (tools/kernels/conv_wino_b3_lds_ring.patch.txt): bit-identical and at parity
-// with this file (profiles/r06_b3_lds_ring_ab.log).  The K loop is not waiting for latency: one wave per SIMD issues ~920 instructions
+// with this file (profiles/r06_b3_lds_ring_ab.log).  The K loop is not waiting for latency: one wave per SIMD issues ~770 instructions
 // per step at 4-10 cycles each, and the workgroups pull 8 TB/s out of the L2s.  Built with -fno-slp-vectorize
 // (build.sh): v_pk_add_f32 / v_pk_fma_f32 take 11 cycles of the wave's issue time, the scalar pair 8 (tools/micro/mfma_shadow.hip).
 constexpr int BPIXQ = 5;        // 16-byte quads per staged pixel: 16 channels + 4 floats of padding
