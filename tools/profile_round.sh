@@ -33,7 +33,7 @@ bash tools/pmc_dist.sh > $R/${RN}_pmc_dist.json 2> $R/pmc_dist.err || echo "pmc_
 bash tools/pmc_netc.sh > $R/${RN}_pmc_netc.json 2> $R/pmc_netc.err || echo "pmc_netc failed"
 # micro-benchmarks: a build failure is shown and the benchmark skipped (no stale binary is run); one killed at its limit (a hung
 # kernel) ends the script -- nothing further may touch the GPU after that
-for m in wave_simd mfma_chain mfma_neighbour ws_step ws_stall ws_gap ws_flag wino_bf16_loop; do
+for m in wave_simd mfma_chain mfma_neighbour ws_step ws_stall ws_gap ws_flag wino_bf16_loop mfma_shadow; do
   if [ ! -x tools/micro/$m ] || [ tools/micro/$m.hip -nt tools/micro/$m ]; then
     hipcc --offload-arch=gfx950 -O3 -w tools/micro/$m.hip -o tools/micro/$m || { echo "build of tools/micro/$m failed: skipped"; rm -f tools/micro/$m; continue; }
   fi
