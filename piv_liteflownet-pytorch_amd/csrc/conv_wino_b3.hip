@@ -44,6 +44,9 @@
 #include "common.h"
 #include "wino_common.h"
 
+#ifndef B3_PLANE_ORDER
+#define B3_PLANE_ORDER 0   // 1: plane columns of a step multiplied in the order 0, 2, 1, 3 instead of 0, 3, 1, 2 (1 % slower: see B3_JB)
+#endif
 #ifndef B3_GINNER
 #define B3_GINNER 0      // 1: a workgroup takes the channel groups of a spatial tile one after the other (measured 1-2 % SLOWER: profiles/r06_b3_group_order_ab.log)
 #endif
@@ -370,36 +373,47 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     do {                                                                                          \
         if (B3_PATCH_POS == (POS)) B3_LOADP(pr);                                                  \
     } while (0)
-#define B3_STEP(WNEXT)                                                                         \
+// Order of a step's plane columns.  Column j needs the row-combined patch columns t: 0: t0 - t2, 1: t1 + t2, 2: t2 - t1, 3: t1 - t3, and
+// the NEXT step's t replace the current ones as they die.  In the order 0, 3, 1, 2 (shipped) t2 is reloaded at the end of the phase in
+// front of its first use; the order 0, 2, 1, 3 gives every reload a whole phase between its LDS reads and its first use -- and measures
+// 1 % slower on every layer (same bits; profiles/r06_b3_plane_order_ab.log): the LDS waits (7 % of the wave cycles) are not these.
+#if B3_PLANE_ORDER
+#define B3_JB 2     // multiplied in phase B (operands produced in A)
+#define B3_JD 3     // multiplied in phase D (operands produced in C)
+#else
+#define B3_JB 3
+#define B3_JD 2
+#endif
+#define B3_STEP(WNEXT)                                                                            \
     do {                                                                                          \
         B3_WAITVM();                                                                              \
         B3_PATCH_AT(0);                                                                           \
-        B3_ULOAD(woff, 3, 1);                                                                     \
+        B3_ULOAD(woff, B3_JB, 1);                                                                 \
         B3_PATCH_AT(1);                                                                           \
-        B3_VPLANE(3, 1);                                                                          \
-        B3_MFMAS(0, 0);                                                                        \
+        B3_VPLANE(B3_JB, 1);                                                                      \
+        B3_MFMAS(0, 0);                                                                           \
         B3_TCOL(0, bo1);                                                                          \
         BSTAMP(8);                                                                                \
         B3_WAITVM();                                                                              \
         B3_ULOAD(woff, 1, 0);                                                                     \
         B3_PATCH_AT(2);                                                                           \
         B3_VPLANE(1, 0);                                                                          \
-        B3_MFMAS(3, 1);                                                                        \
-        B3_TCOL(3, bo1);                                                                          \
+        B3_MFMAS(B3_JB, 1);                                                                       \
+        B3_TCOL(B3_JB, bo1);                                                                      \
         BSTAMP(9);                                                                                \
         B3_WAITVM();                                                                              \
-        B3_ULOAD(woff, 2, 1);                                                                     \
+        B3_ULOAD(woff, B3_JD, 1);                                                                 \
         B3_PATCH_AT(3);                                                                           \
-        B3_VPLANE(2, 1);                                                                          \
-        B3_MFMAS(1, 0);                                                                        \
+        B3_VPLANE(B3_JD, 1);                                                                      \
+        B3_MFMAS(1, 0);                                                                           \
         B3_TCOL(1, bo1);                                                                          \
-        B3_TCOL(2, bo1);                                                                          \
+        B3_TCOL(B3_JD, bo1);                                                                      \
         BSTAMP(10);                                                                               \
         B3_WAITVM();                                                                              \
         woff = (WNEXT);                                                                           \
         B3_ULOAD(woff, 0, 0);                                                                     \
         B3_VPLANE(0, 0);                                                                          \
-        B3_MFMAS(2, 1);                                                                        \
+        B3_MFMAS(B3_JD, 1);                                                                       \
         BSTAMP(11);                                                                               \
         B3_COMMIT(pr, bo2);                                                                       \
         __syncthreads();                                                                          \
@@ -412,24 +426,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
     do {                                                                                          \
         B3_WAITVM();                                                                              \
         B3_PATCH_AT(0);                                                                           \
-        B3_ULOAD(woff, 3, 1);                                                                     \
+        B3_ULOAD(woff, B3_JB, 1);                                                                 \
         B3_PATCH_AT(1);                                                                           \
-        B3_VPLANE(3, 1);                                                                          \
-        B3_MFMAS(0, 0);                                                                    \
+        B3_VPLANE(B3_JB, 1);                                                                      \
+        B3_MFMAS(0, 0);                                                                           \
         B3_WAITVM();                                                                              \
         B3_ULOAD(woff, 1, 0);                                                                     \
         B3_PATCH_AT(2);                                                                           \
         B3_VPLANE(1, 0);                                                                          \
-        B3_MFMAS(3, 1);                                                                    \
+        B3_MFMAS(B3_JB, 1);                                                                       \
         B3_WAITVM();                                                                              \
-        B3_ULOAD(woff, 2, 1);                                                                     \
+        B3_ULOAD(woff, B3_JD, 1);                                                                 \
         B3_PATCH_AT(3);                                                                           \
-        B3_VPLANE(2, 1);                                                                          \
-        B3_MFMAS(1, 0);                                                                    \
+        B3_VPLANE(B3_JD, 1);                                                                      \
+        B3_MFMAS(1, 0);                                                                           \
         B3_WAITVM();                                                                              \
         woff = (WNEXT);                                                                           \
         B3_ULOAD(woff, 0, 0);                                                                     \
-        B3_MFMAS(2, 1);                                                                    \
+        B3_MFMAS(B3_JD, 1);                                                                       \
         B3_COMMIT(pr, bo2);                                                                       \
         __syncthreads();                                                                          \
         const int tt_ = bo1; bo1 = bo2; bo2 = tt_;                                                \
