@@ -207,11 +207,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
         ly0 = lty * 16;                                                                           \
         const int lb_ = lb;                                                                       \
         lrow0 = ly0 - 1;                                                                          \
+        const long pix0_ = (long)lb_ * (long)img_px + (long)lrow0 * p.W;       /* first pixel of the patch's first image row */ \
+        const size_t pixl_ = (size_t)(p.H - lrow0) * p.W - 1;                   /* pixels from there to the image's last one */ \
         _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                           \
-            const int ss = s < p.nseg ? s : 0;                                                    \
-            const size_t left = ((size_t)(p.H - lrow0) * p.W - 1) * p.seg[ss].stride + p.seg[ss].cload; \
-            rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[ss].ptr) + ((long)lb_ * (long)img_px + (long)lrow0 * p.W) * p.seg[ss].stride, 0, \
-                                                       (unsigned)min(left * 4, (size_t)0x7fffffff), 0x00020000); \
+            if (s == 0 || s < p.nseg) {     /* single-source layers (most) pay for one descriptor, not three */ \
+                const size_t left = pixl_ * p.seg[s].stride + p.seg[s].cload;                     \
+                rsv[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[s].ptr) + pix0_ * p.seg[s].stride, 0, \
+                                                           (unsigned)min(left * 4, (size_t)0x7fffffff), 0x00020000); \
+            } else {                                                                              \
+                rsv[s] = rsv[0];                                                                  \
+            }                                                                                     \
         }                                                                                         \
         lseg = 0; lc0 = 0; lscl = p.seg[0].cload;                                                 \
         B3_PVO(0);                                                                                \
