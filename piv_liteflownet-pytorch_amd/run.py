@@ -61,7 +61,7 @@ parser.add_argument("--no_cuda", action="store_true")
 parser.add_argument("--weights", type=str, default=None, help="state dict file (torch.load); default: seeded synthetic weights")
 parser.add_argument("--synthetic_weights", action="store_true")
 parser.add_argument("--batch", type=int, default=4, help="pairs per forward")
-parser.add_argument("--precision", type=str, default=None, choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"],
+parser.add_argument("--precision", type=str, default=None, choices=["fp32", "fp32_wino_mfma32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"],
                     help="how the large convolutions multiply (not a reference flag; default: the library's, fp32 -- "
                          "see Network.precision)")
 

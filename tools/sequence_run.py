@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--write", default=None, help="directory for rank 0's .flo files")
     ap.add_argument("--null-sink", action="store_true", help="hand every flow to a sink that drops it (the loop without the disk)")
     ap.add_argument("--no-gather", action="store_true", help="no all-gather: every rank hands its own shard to its own sink / writer")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_wino_mfma32", "fp32_direct", "fp32_split", "fp32_split3", "fp16"])
     ap.add_argument("--model", default="piv")
     ap.add_argument("--seed", type=int, default=99)
     a = ap.parse_args()
