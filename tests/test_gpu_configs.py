@@ -174,7 +174,8 @@ def _run_children(cmd_for_rank, world, env_extra, timeout=900):
 
 def test_config3_sequence_two_rank_rehearsal(tmp_path, dev):
     """The 2-rank control flow of config #4 on one GPU (gloo instead of RCCL, both ranks on device 0): contiguous shards, halo
-    frame, per-chunk all-gather, rank 0 writes -- the same .flo set, bit for bit, as estimate() pair by pair."""
+    frame, per-chunk all-gather, rank 0 writes -- the same .flo set, bit for bit, as estimate() pair by pair, and the pairs at the
+    shard boundary within the end-to-end tolerance of the CPU oracle."""
     from pivlfn.sequence import flow_file_name
     n_frames, S = 8, 512                                            # 7 pairs: shards of 4 and 3, chunk 3 -> a short last chunk
     outdir = tmp_path / "flow2"
@@ -187,6 +188,15 @@ def test_config3_sequence_two_rank_rehearsal(tmp_path, dev):
     assert sorted(os.listdir(outdir)) == [flow_file_name(k) for k in range(7)]
     for k in range(7):
         assert np.array_equal(read_flow(str(outdir / flow_file_name(k))), want[k]), f"pair {k}"
+    # ... and not only equal to the library's own estimate(): the two pairs either side of the shard boundary (pair 3 is rank 0's
+    # last, pair 4 is rank 1's first and starts at its halo frame) against the oracle's estimate() on the CPU, from the same frames
+    from pivlfn.sequence import frames_to_input
+    x = frames_to_input(synth.ParticleSequence(S, S, seed=7, device=dev).frames(3, 6)).cpu()
+    onet = orc.make_net("piv", synth.generate_weights("piv", 0), corr="c")
+    for j, k in enumerate((3, 4)):
+        with torch.no_grad():
+            ow = orc.estimate(onet, x[j:j + 1], x[j + 1:j + 2], tensor=False)
+        _check(read_flow(str(outdir / flow_file_name(k))), ow, f"2-rank sequence pair {k} vs oracle")
 
 
 def test_bench_py_two_rank_rehearsal(dev):
