@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_b3_kernel(const ConvParamsW 
 #define B3_ABL_UOFF(V) (V)
 #endif
 #ifndef B3_PATCH_POS
-#define B3_PATCH_POS 3      // behind the fragment loads of phase 2: -3 % against position 0 (tools/bench_b3.py, same box), no spill in any instance
+// behind the fragment loads of phase 1 with six terms (1.4-2.6 % faster than phase 2, -3 % and more against position 0: tools/bench_b3.py,
+// same box, profiles/r06_b3_patch_pos_ab.log); the eight- and nine-term instances spill there and keep phase 2 -- no spill in any instance
+#define B3_PATCH_POS (TERMS == 6 ? 2 : 3)
 #endif
 #ifndef B3_BRANCHFREE
 #define B3_BRANCHFREE 1
